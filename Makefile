@@ -1,0 +1,34 @@
+# Top-level build: HIP library (gfx950), plain-C host driver, CPU oracle (test infrastructure).
+HIPCC ?= /opt/rocm/bin/hipcc
+CC ?= gcc
+PKG = ray-tracing_amd
+LIBDIR = $(PKG)/lib
+HIPFLAGS = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fvisibility=hidden -Wall
+CFLAGS = -std=gnu11 -O2 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wextra
+
+HIP_SRCS = $(wildcard $(PKG)/csrc/*.hip)
+HIP_HDRS = $(wildcard $(PKG)/csrc/*.h) $(wildcard include/*.h)
+
+all: $(LIBDIR)/librt_amd.so $(LIBDIR)/librt_host.so $(LIBDIR)/rt_render oracle
+
+$(LIBDIR)/librt_amd.so: $(HIP_SRCS) $(HIP_HDRS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS)
+
+$(LIBDIR)/librt_host.so: $(PKG)/host/rt_host.c $(PKG)/host/rt_host.h include/rt_abi.h
+	@mkdir -p $(LIBDIR)
+	$(CC) $(CFLAGS) -shared -o $@ $(PKG)/host/rt_host.c -lm
+
+$(LIBDIR)/rt_render: $(PKG)/host/rt_cli.c $(PKG)/host/rt_renderer.c $(PKG)/host/rt_renderer.h $(LIBDIR)/librt_amd.so $(LIBDIR)/librt_host.so
+	$(CC) $(CFLAGS) -o $@ $(PKG)/host/rt_cli.c $(PKG)/host/rt_renderer.c -L$(LIBDIR) -lrt_host -lrt_amd -lm -Wl,-rpath,'$$ORIGIN'
+
+oracle:
+	$(MAKE) -C oracle
+
+host: $(LIBDIR)/librt_host.so
+
+clean:
+	rm -f $(LIBDIR)/*.so $(LIBDIR)/rt_render
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle host clean
