@@ -1,0 +1,139 @@
+/*
+ * rt_amd.h -- C-ABI of the MI355X path-tracing library (librt_amd.so).
+ *
+ * The reference has no plugin or FFI interface: its boundary is the Metal binding
+ * contract of one compute kernel (texture(0) = rgba32Float render target,
+ * buffer(0) = one `Uniforms`, buffer(1) = `Object[objCount]`; reference:
+ * "Ray Tracer/Shaders.metal":91-94) and the Swift methods of `MetalRenderer`
+ * that drive it (reference: "Ray Tracer/ContentView.swift":232-752).  Each entry
+ * point below names the reference call it replaces.  Struct layouts are those of
+ * the reference's bridging header (see rt_abi.h).
+ *
+ * All functions return RT_OK (0) or a negative RT_ERR_* code; rt_last_error()
+ * gives a message for the last failure on that context.  Host pointers passed in
+ * are copied before the call returns (the reference re-sends uniforms and objects
+ * with setBytes on every dispatch, ContentView.swift:689-696); nothing is retained.
+ * A context is used from one host thread at a time, like the reference's renderer,
+ * which is driven from the main run loop only (ContentView.swift:617-619).
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stdint.h>
+
+#include "rt_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(_WIN32)
+#define RT_API
+#else
+#define RT_API __attribute__((visibility("default")))
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+enum {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,    /* bad argument */
+    RT_ERR_NO_DEVICE = -2,  /* no usable GPU / HIP runtime failure at create */
+    RT_ERR_HIP = -3,        /* a HIP call failed; see rt_last_error */
+    RT_ERR_NO_TARGET = -4,  /* rt_set_target has not been called */
+    RT_ERR_NO_SCENE = -5,   /* no objects given and none resident */
+    RT_ERR_TOO_LARGE = -6   /* size beyond what the entry point supports */
+};
+
+/* Option keys for rt_set_option. */
+enum {
+    RT_OPT_CHUNK = 1,       /* samples per work item of the batch path; 0 = all samples of a call in one
+                               item, which reproduces the reference's sequential per-pixel sum order */
+    RT_OPT_ARITH = 2,       /* 0 = strict (no fused multiply-add anywhere; bit-identical intersection
+                               decisions to an uncontracted IEEE evaluation), 1 = fused multiply-add in the
+                               sphere discriminant */
+    RT_OPT_KERNEL = 3,      /* 0 = persistent megakernel, 1 = wavefront (generate/extend/shade queues) */
+    RT_OPT_SCENE_FETCH = 4, /* 0 = spheres staged in LDS per workgroup, 1 = spheres read through the scalar
+                               cache from global memory */
+    RT_OPT_BLOCKS_PER_CU = 5 /* persistent grid size = this x compute units; 0 = occupancy query */
+};
+
+/* setupMetal (ContentView.swift:328-356): device, queue, pipelines.  `device` is the HIP device ordinal.
+ * `stream` is a hipStream_t the library should enqueue on, or NULL to create its own. */
+RT_API int rt_create(rt_ctx **out, int device, void *stream);
+RT_API void rt_destroy(rt_ctx *ctx);
+RT_API const char *rt_last_error(const rt_ctx *ctx);
+RT_API int rt_set_option(rt_ctx *ctx, int key, int value);
+RT_API int rt_get_option(const rt_ctx *ctx, int key, int *value);
+
+/* setupTexture(width:height:) (ContentView.swift:358-378): allocate the rgba32Float render target and
+ * fill it with (0,0,0,1). */
+RT_API int rt_set_target(rt_ctx *ctx, int width, int height);
+/* clearTexture() (ContentView.swift:661-664). */
+RT_API int rt_clear(rt_ctx *ctx);
+/* updateTexture() (ContentView.swift:509-518): replace the whole target with host pixels (rgba float). */
+RT_API int rt_write_target(rt_ctx *ctx, const float *rgba);
+/* No counterpart (the reference never reads the texture back): copy the target to host, rgba float,
+ * row 0 first. */
+RT_API int rt_read_target(rt_ctx *ctx, float *rgba);
+
+/* runComputeShaderForTile(tile:sampleIndex:) (ContentView.swift:666-709) + computeShader
+ * (Shaders.metal:91-161).  The caller fills currentSample, objCount and the tile rectangle of *u exactly
+ * as the Swift method does (:678-687).  One pass of u->sampleCount samples per pixel of the tile is traced
+ * and blended into the target with the reference's gamma-encoded running mean (Shaders.metal:144-160).
+ * Blocks until the GPU is done, like commit + waitUntilCompleted (:707-708).  The reference's yellow
+ * error pixels (Shaders.metal:99-114: threads of the 8x8 groups outside the tile, pixels outside the
+ * target, currentSample > 10000) are written at the same texels; the return value is then 1 instead of 0. */
+RT_API int rt_render_tile(rt_ctx *ctx, const struct Uniforms *u, const struct Object *objs, int objCount);
+
+/* draw(in:) (ContentView.swift:575-598) + Present.metal:16-44: nearest-sample the target into an
+ * out_w x out_h bgra8Unorm image (row 0 = top), returned to host memory. */
+RT_API int rt_present_bgra8(rt_ctx *ctx, uint8_t *out, int out_w, int out_h);
+
+/* ---- batch path: same kernel semantics, whole image per call, linear accumulation ---------------- */
+
+/* Upload and keep the object array on the device (the reference's `objects`, ContentView.swift:239);
+ * later calls may pass objs = NULL to use it. */
+RT_API int rt_set_scene(rt_ctx *ctx, const struct Object *objs, int objCount);
+
+/* Trace samples rayIndex in [ray_begin, ray_end) of pass u->currentSample for every pixel of the tile
+ * rectangle in *u (normally the whole target), each sample exactly as one trip of the loop at
+ * Shaders.metal:120-140, and ADD their linear sums into `accum_dev`, a device buffer of
+ * width*height float4 (row-major, rgba), or into the context's own buffer when accum_dev is NULL.
+ * Enqueued on the context's stream; returns without waiting. */
+RT_API int rt_render(rt_ctx *ctx, const struct Uniforms *u, const struct Object *objs, int objCount, int ray_begin,
+                     int ray_end, float *accum_dev);
+/* Zero an accumulation buffer (the context's own when NULL).  Enqueued on the stream. */
+RT_API int rt_accum_clear(rt_ctx *ctx, float *accum_dev);
+/* Device address of the context's own accumulation buffer (width*height*4 floats). */
+RT_API int rt_accum_ptr(rt_ctx *ctx, float **accum_dev);
+/* accum / spp -> NaN scrub, clamp to [0,1], sqrt (write_color, Shaders.metal:71-85; Lib.metal:144-150)
+ * -> target.  This is what computeShader stores for currentSample == 0.  Enqueued on the stream. */
+RT_API int rt_resolve(rt_ctx *ctx, const float *accum_dev, int spp);
+/* Wait for everything enqueued on the context's stream. */
+RT_API int rt_synchronize(rt_ctx *ctx);
+
+/* First-hit buffer of sample (u->currentSample, rayIndex 0): camera ray (Lib.metal:99-106) + closest hit
+ * (Shaders.metal:13-32).  out4 = width*height x {t, nx, ny, nz}; ids = object index or -1.  Host buffers.
+ * Blocks. */
+RT_API int rt_first_hit(rt_ctx *ctx, const struct Uniforms *u, const struct Object *objs, int objCount, float *out4,
+                        int32_t *ids);
+
+/* Counters of the last rt_render / rt_render_tile call: segments = closest-hit searches (world_hit calls),
+ * tests = ray-object tests the reference's brute-force loop performs for them (segments x objCount),
+ * kernel_ms = device time of the trace kernel(s) from HIP events on the context's stream.  Blocks until
+ * that call has finished. */
+struct rt_stats {
+    uint64_t segments;
+    uint64_t tests;
+    uint64_t samples;
+    float kernel_ms;
+    int grid_blocks;
+    int block_threads;
+};
+RT_API int rt_last_stats(rt_ctx *ctx, struct rt_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

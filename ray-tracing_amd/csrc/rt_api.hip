@@ -1,0 +1,564 @@
+// rt_api.hip -- the C-ABI of librt_amd.so (declared in include/rt_amd.h): context, render target, scene
+// upload and compaction, and the calls that enqueue the kernels of rt_kernels.hip.
+//
+// Host-side mirror of what the reference's MetalRenderer does around its compute dispatch
+// (reference: "Ray Tracer/ContentView.swift":328-378, 661-709).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_amd.h"
+#include "rt_kernels.h"
+
+using namespace rt;
+
+namespace {
+template <typename T>
+struct DevBuf {
+    T *ptr = nullptr;
+    size_t cap = 0;  // elements
+};
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    int num_cus = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    int width = 0, height = 0;
+    DevBuf<float4> target, accum, planes;
+
+    // compact scene
+    DevBuf<float4> sph;
+    DevBuf<float> rad;
+    DevBuf<int> sph_obj;
+    DevBuf<QuadDev> quads;
+    DevBuf<MatDev> mats;
+    int nsph = 0, nsph_pad = 0, nquad = 0, nobj = 0;
+    bool scene_resident = false;
+
+    uint32_t *counters = nullptr;  // 256 B: [0] work counter (u32), [2..3] segment counter (u64)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool stats_pending = false;
+
+    int opt_chunk = 64;
+    int opt_arith = 0;
+    int opt_kernel = 0;
+    int opt_fetch = 0;
+    int opt_blocks_per_cu = 0;
+
+    rt_stats last = {};
+    std::string err;
+};
+
+namespace {
+
+// Largest sphere count staged in LDS (16 B each): 4096 spheres = 64 KiB, which leaves room for two
+// workgroups per compute unit in the 160 KiB LDS.  Larger scenes are read through the scalar cache.
+constexpr int kMaxLdsSpheres = 4096;
+
+int fail(rt_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
+    if (c) {
+        c->err = what;
+        if (e != hipSuccess) {
+            c->err += ": ";
+            c->err += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define RT_HIP(call)                                                    \
+    do {                                                                \
+        hipError_t e_ = (call);                                         \
+        if (e_ != hipSuccess) return fail(ctx, RT_ERR_HIP, #call, e_);  \
+    } while (0)
+
+#define RT_TRY(expr)                   \
+    do {                               \
+        int rc_ = (expr);              \
+        if (rc_ < 0) return rc_;       \
+    } while (0)
+
+struct Bind {  // make the context's device current for the duration of a call
+    int prev = -1;
+    explicit Bind(rt_ctx *c) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != c->device) (void)hipSetDevice(c->device);
+    }
+    ~Bind() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+V3 ld3(const rt_float3 &a) { V3 r; r.x = a.x; r.y = a.y; r.z = a.z; return r; }
+V4 ld4(const rt_float4 &a) { V4 r; r.x = a.x; r.y = a.y; r.z = a.z; r.w = a.w; return r; }
+
+template <typename T>
+int grow(rt_ctx *ctx, DevBuf<T> &b, size_t need) {
+    if (need <= b.cap) return RT_OK;
+    if (b.ptr) RT_HIP(hipFree(b.ptr));
+    b.ptr = nullptr;
+    b.cap = 0;
+    RT_HIP(hipMalloc((void **)&b.ptr, need * sizeof(T)));
+    b.cap = need;
+    return RT_OK;
+}
+
+template <typename T>
+int upload(rt_ctx *ctx, DevBuf<T> &b, const std::vector<T> &h) {
+    RT_TRY(grow(ctx, b, h.size() ? h.size() : 1));
+    if (!h.empty()) RT_HIP(hipMemcpyAsync(b.ptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return RT_OK;
+}
+
+// Object[] (160-byte AoS records) -> compact device arrays.  Sphere slots keep the objects' relative order;
+// the slot count is padded to a multiple of 32 with records that can never be hit.
+int upload_scene(rt_ctx *ctx, const Object *objs, int n) {
+    if (n < 0 || (n > 0 && !objs)) return fail(ctx, RT_ERR_INVALID, "rt: bad object array");
+    std::vector<float4> sph;
+    std::vector<float> rad;
+    std::vector<int> sph_obj;
+    std::vector<QuadDev> quads;
+    std::vector<MatDev> mats((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const Object &o = objs[i];
+        MatDev m;
+        m.albedo = ld4(o.mat.albedo);
+        if (o.mat.emission > 0.0f) {  // Shaders.metal:51-54
+            m.emis.x = o.mat.emission_color.x * o.mat.emission;
+            m.emis.y = o.mat.emission_color.y * o.mat.emission;
+            m.emis.z = o.mat.emission_color.z * o.mat.emission;
+            m.emis.w = o.mat.emission_color.w * o.mat.emission;
+        } else {
+            m.emis.x = 0.0f; m.emis.y = 0.0f; m.emis.z = 0.0f; m.emis.w = 1.0f;
+        }
+        m.type = o.mat.type;
+        m.fuzz = o.mat.reflection_fuzz;
+        m.ior = o.mat.refraction_index;
+        m.inv_ior = 1.0f / o.mat.refraction_index;  // Lib.metal:185
+        mats[(size_t)i] = m;
+        if (o.type == TYPE_SPHERE) {
+            sph.push_back(make_float4(o.s.center.x, o.s.center.y, o.s.center.z, o.s.radius * o.s.radius));
+            rad.push_back(o.s.radius);
+            sph_obj.push_back(i);
+        } else if (o.type == TYPE_QUAD) {
+            QuadDev q;
+            q.origin = ld3(o.q.origin); q.obj = i;
+            q.ex = ld3(o.q.extentX); q.pad0 = 0.0f;
+            q.ey = ld3(o.q.extentY); q.pad1 = 0.0f;
+            quads.push_back(q);
+        }  // any other type never hits (Lib.metal:283-291)
+    }
+    int nsph = (int)sph.size();
+    int nsph_pad = (nsph + 31) / 32 * 32;
+    if (nsph_pad == 0) nsph_pad = 32;
+    const float ninf = -std::numeric_limits<float>::infinity();
+    while ((int)sph.size() < nsph_pad) {
+        sph.push_back(make_float4(0.0f, 0.0f, 0.0f, ninf));
+        rad.push_back(1.0f);
+        sph_obj.push_back(-1);
+    }
+    RT_TRY(upload(ctx, ctx->sph, sph));
+    RT_TRY(upload(ctx, ctx->rad, rad));
+    RT_TRY(upload(ctx, ctx->sph_obj, sph_obj));
+    RT_TRY(upload(ctx, ctx->quads, quads));
+    RT_TRY(upload(ctx, ctx->mats, mats));
+    // the host vectors die at return: wait for the copies
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->nsph = nsph;
+    ctx->nsph_pad = nsph_pad;
+    ctx->nquad = (int)quads.size();
+    ctx->nobj = n;
+    return RT_OK;
+}
+
+// Scene of one call.  objs != NULL: copy the first u->objCount objects (the reference's kernel loops over
+// uniforms.objCount, Shaders.metal:135, and the host sends that many, ContentView.swift:682-696); this
+// replaces any resident scene.  objs == NULL: use the scene kept by rt_set_scene.
+int scene_for_call(rt_ctx *ctx, const Uniforms *u, const Object *objs, int objCount) {
+    if (objs) {
+        if (u->objCount < 0 || u->objCount > objCount)
+            return fail(ctx, RT_ERR_INVALID, "rt: uniforms.objCount must be within [0, objCount]");
+        ctx->scene_resident = false;
+        return upload_scene(ctx, objs, u->objCount);
+    }
+    if (!ctx->scene_resident) return fail(ctx, RT_ERR_NO_SCENE, "rt: objs is NULL and no scene was set with rt_set_scene");
+    return RT_OK;
+}
+
+void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
+    std::memset(&P, 0, sizeof P);
+    P.cam.pixelOrigin = ld3(u->pixelOrigin);
+    P.cam.pixelDeltaX = ld3(u->pixelDeltaX);
+    P.cam.pixelDeltaY = ld3(u->pixelDeltaY);
+    P.cam.cameraCenter = ld3(u->cameraCenter);
+    P.cam.defocusDiskU = ld3(u->defocusDiskU);
+    P.cam.defocusDiskV = ld3(u->defocusDiskV);
+    P.cam.defocusAngle = u->defocusAngle;
+    P.sky = ld4(u->globalIllumation);
+    P.sph = ctx->sph.ptr;
+    P.rad = ctx->rad.ptr;
+    P.sph_obj = ctx->sph_obj.ptr;
+    P.quads = ctx->quads.ptr;
+    P.mats = ctx->mats.ptr;
+    P.nsph = ctx->nsph;
+    P.nsph_pad = ctx->nsph_pad;
+    P.nquad = ctx->nquad;
+    P.nobj = ctx->nobj;
+    P.width = ctx->width;
+    P.height = ctx->height;
+    P.pass = u->currentSample;
+    P.maxDepth = u->maxRayDepth;
+    P.counter = ctx->counters;
+    P.seg_counter = (unsigned long long *)(ctx->counters + 2);
+    P.target = ctx->target.ptr;
+}
+
+// Enqueue one trace launch (counter reset, events, kernel).
+int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
+    const bool fast = ctx->opt_arith != 0;
+    const bool lds_scene = ctx->opt_fetch == 0 && P.nsph_pad <= kMaxLdsSpheres;
+    const size_t lds_bytes = lds_scene ? (size_t)P.nsph_pad * sizeof(float4) : 0;
+    int per_cu = ctx->opt_blocks_per_cu > 0 ? ctx->opt_blocks_per_cu : trace_blocks_per_cu(fast, lds_scene, lds_bytes);
+    long long blocks = (long long)per_cu * ctx->num_cus;
+    long long need = ((long long)P.nitems + 255) / 256;
+    if (blocks > need) blocks = need;
+    if (blocks < 1) blocks = 1;
+    RT_HIP(hipMemsetAsync(ctx->counters, 0, 256, ctx->stream));
+    RT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    RT_HIP(launch_trace(P, fast, lds_scene, (int)blocks, ctx->stream));
+    RT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->stats_pending = true;
+    ctx->last = {};
+    ctx->last.grid_blocks = (int)blocks;
+    ctx->last.block_threads = 256;
+    return RT_OK;
+}
+
+}  // namespace
+
+// ---- exported C-ABI -------------------------------------------------------------------------------------
+
+extern "C" {
+
+RT_API int rt_create(rt_ctx **out, int device, void *stream) {
+    if (!out) return RT_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return RT_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return RT_ERR_NO_DEVICE;
+    rt_ctx *ctx = new rt_ctx();
+    ctx->device = device;
+    Bind bind(ctx);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        delete ctx;
+        return RT_ERR_NO_DEVICE;
+    }
+    ctx->num_cus = prop.multiProcessorCount;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return RT_ERR_NO_DEVICE;
+        }
+        ctx->own_stream = true;
+    }
+    if (hipMalloc((void **)&ctx->counters, 256) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
+        hipEventCreate(&ctx->ev1) != hipSuccess) {
+        rt_destroy(ctx);
+        return RT_ERR_HIP;
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+RT_API void rt_destroy(rt_ctx *ctx) {
+    if (!ctx) return;
+    Bind bind(ctx);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->target.ptr);
+    (void)hipFree(ctx->accum.ptr);
+    (void)hipFree(ctx->planes.ptr);
+    (void)hipFree(ctx->sph.ptr);
+    (void)hipFree(ctx->rad.ptr);
+    (void)hipFree(ctx->sph_obj.ptr);
+    (void)hipFree(ctx->quads.ptr);
+    (void)hipFree(ctx->mats.ptr);
+    (void)hipFree(ctx->counters);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+RT_API const char *rt_last_error(const rt_ctx *ctx) { return ctx ? ctx->err.c_str() : "rt: null context"; }
+
+RT_API int rt_set_option(rt_ctx *ctx, int key, int value) {
+    if (!ctx) return RT_ERR_INVALID;
+    switch (key) {
+        case RT_OPT_CHUNK:
+            if (value < 0) return fail(ctx, RT_ERR_INVALID, "rt: chunk must be >= 0");
+            ctx->opt_chunk = value;
+            return RT_OK;
+        case RT_OPT_ARITH:
+            if (value != 0 && value != 1) return fail(ctx, RT_ERR_INVALID, "rt: arith must be 0 or 1");
+            ctx->opt_arith = value;
+            return RT_OK;
+        case RT_OPT_KERNEL:
+            if (value != 0) return fail(ctx, RT_ERR_INVALID, "rt: kernel variant not available");
+            ctx->opt_kernel = value;
+            return RT_OK;
+        case RT_OPT_SCENE_FETCH:
+            if (value != 0 && value != 1) return fail(ctx, RT_ERR_INVALID, "rt: scene fetch must be 0 or 1");
+            ctx->opt_fetch = value;
+            return RT_OK;
+        case RT_OPT_BLOCKS_PER_CU:
+            if (value < 0 || value > 64) return fail(ctx, RT_ERR_INVALID, "rt: blocks per CU out of range");
+            ctx->opt_blocks_per_cu = value;
+            return RT_OK;
+    }
+    return fail(ctx, RT_ERR_INVALID, "rt: unknown option");
+}
+
+RT_API int rt_get_option(const rt_ctx *ctx, int key, int *value) {
+    if (!ctx || !value) return RT_ERR_INVALID;
+    switch (key) {
+        case RT_OPT_CHUNK: *value = ctx->opt_chunk; return RT_OK;
+        case RT_OPT_ARITH: *value = ctx->opt_arith; return RT_OK;
+        case RT_OPT_KERNEL: *value = ctx->opt_kernel; return RT_OK;
+        case RT_OPT_SCENE_FETCH: *value = ctx->opt_fetch; return RT_OK;
+        case RT_OPT_BLOCKS_PER_CU: *value = ctx->opt_blocks_per_cu; return RT_OK;
+    }
+    return RT_ERR_INVALID;
+}
+
+RT_API int rt_set_target(rt_ctx *ctx, int width, int height) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 28))
+        return fail(ctx, RT_ERR_INVALID, "rt: bad target size");
+    Bind bind(ctx);
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    size_t n = (size_t)width * height;
+    RT_TRY(grow(ctx, ctx->target, n));
+    RT_TRY(grow(ctx, ctx->accum, n));
+    ctx->width = width;
+    ctx->height = height;
+    RT_TRY(rt_clear(ctx));
+    RT_TRY(rt_accum_clear(ctx, nullptr));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+RT_API int rt_clear(rt_ctx *ctx) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->target.ptr) return fail(ctx, RT_ERR_NO_TARGET, "rt: no render target");
+    Bind bind(ctx);
+    RT_HIP(launch_fill_rect(ctx->target.ptr, ctx->width, ctx->height, 0, 0, ctx->width, ctx->height,
+                            make_float4(0.0f, 0.0f, 0.0f, 1.0f), ctx->stream));
+    return RT_OK;
+}
+
+RT_API int rt_write_target(rt_ctx *ctx, const float *rgba) {
+    if (!ctx || !rgba) return RT_ERR_INVALID;
+    if (!ctx->target.ptr) return fail(ctx, RT_ERR_NO_TARGET, "rt: no render target");
+    Bind bind(ctx);
+    RT_HIP(hipMemcpyAsync(ctx->target.ptr, rgba, (size_t)ctx->width * ctx->height * sizeof(float4), hipMemcpyHostToDevice,
+                          ctx->stream));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+RT_API int rt_read_target(rt_ctx *ctx, float *rgba) {
+    if (!ctx || !rgba) return RT_ERR_INVALID;
+    if (!ctx->target.ptr) return fail(ctx, RT_ERR_NO_TARGET, "rt: no render target");
+    Bind bind(ctx);
+    RT_HIP(hipMemcpyAsync(rgba, ctx->target.ptr, (size_t)ctx->width * ctx->height * sizeof(float4), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+RT_API int rt_set_scene(rt_ctx *ctx, const Object *objs, int objCount) {
+    if (!ctx) return RT_ERR_INVALID;
+    Bind bind(ctx);
+    ctx->scene_resident = false;
+    RT_TRY(upload_scene(ctx, objs, objCount));
+    ctx->scene_resident = true;
+    return RT_OK;
+}
+
+RT_API int rt_render_tile(rt_ctx *ctx, const Uniforms *u, const Object *objs, int objCount) {
+    if (!ctx || !u) return RT_ERR_INVALID;
+    if (!ctx->target.ptr) return fail(ctx, RT_ERR_NO_TARGET, "rt: no render target");
+    if (u->tileWidth <= 0 || u->tileHeight <= 0 || u->tileX < 0 || u->tileY < 0)
+        return fail(ctx, RT_ERR_INVALID, "rt: tile rectangle must have positive size and non-negative origin");
+    Bind bind(ctx);
+    RT_TRY(scene_for_call(ctx, u, objs, objCount));
+
+    // The reference dispatches ceil(tile/8) groups of 8x8 threads (ContentView.swift:698-705).
+    const int gw = (u->tileWidth + 7) / 8 * 8, gh = (u->tileHeight + 7) / 8 * 8;
+    const bool all_fail = u->currentSample > 10000;  // Shaders.metal:111-114
+    const bool clipped = u->tileX + u->tileWidth > ctx->width || u->tileY + u->tileHeight > ctx->height;
+    int status = RT_OK;
+    if (all_fail || clipped || gw != u->tileWidth || gh != u->tileHeight) {
+        RT_HIP(launch_error_pixels(ctx->target.ptr, ctx->width, ctx->height, gw, gh, u->tileX, u->tileY, u->tileWidth,
+                                   u->tileHeight, all_fail ? 1 : 0, ctx->stream));
+        status = 1;
+    }
+    int tw = u->tileWidth, th = u->tileHeight;
+    if (u->tileX + tw > ctx->width) tw = ctx->width - u->tileX;
+    if (u->tileY + th > ctx->height) th = ctx->height - u->tileY;
+    if (!all_fail && tw > 0 && th > 0) {
+        TraceParams P;
+        fill_params(ctx, u, P);
+        P.tileX = u->tileX; P.tileY = u->tileY; P.tileW = tw; P.tileH = th;
+        P.ray_begin = 0;
+        P.ray_end = u->sampleCount > 0 ? u->sampleCount : 0;
+        P.chunk = P.ray_end > 0 ? P.ray_end : 1;
+        P.nitems = (uint32_t)tw * (uint32_t)th;
+        P.mode = kModeProgressive;
+        P.spp_pass = u->sampleCount;
+        RT_TRY(enqueue_trace(ctx, P));
+        ctx->last.samples = (uint64_t)P.nitems * (uint64_t)P.ray_end;
+    }
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    return status;
+}
+
+RT_API int rt_present_bgra8(rt_ctx *ctx, uint8_t *out, int out_w, int out_h) {
+    if (!ctx || !out || out_w <= 0 || out_h <= 0) return RT_ERR_INVALID;
+    if (!ctx->target.ptr) return fail(ctx, RT_ERR_NO_TARGET, "rt: no render target");
+    Bind bind(ctx);
+    uint32_t *dev = nullptr;
+    size_t bytes = (size_t)out_w * out_h * 4;
+    RT_HIP(hipMalloc((void **)&dev, bytes));
+    hipError_t e = launch_present_bgra8(ctx->target.ptr, ctx->width, ctx->height, dev, out_w, out_h, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_present_bgra8", e);
+    return RT_OK;
+}
+
+RT_API int rt_render(rt_ctx *ctx, const Uniforms *u, const Object *objs, int objCount, int ray_begin, int ray_end,
+                     float *accum_dev) {
+    if (!ctx || !u) return RT_ERR_INVALID;
+    if (!ctx->target.ptr) return fail(ctx, RT_ERR_NO_TARGET, "rt: no render target");
+    if (ray_begin < 0 || ray_end < ray_begin) return fail(ctx, RT_ERR_INVALID, "rt: bad ray index range");
+    if (u->tileWidth <= 0 || u->tileHeight <= 0 || u->tileX < 0 || u->tileY < 0 || u->tileX + u->tileWidth > ctx->width ||
+        u->tileY + u->tileHeight > ctx->height)
+        return fail(ctx, RT_ERR_INVALID, "rt: tile rectangle must lie inside the render target");
+    if (u->currentSample > 10000) return fail(ctx, RT_ERR_INVALID, "rt: currentSample > 10000 (the reference paints yellow)");
+    Bind bind(ctx);
+    RT_TRY(scene_for_call(ctx, u, objs, objCount));
+    if (ray_end == ray_begin) return RT_OK;
+
+    const int nrays = ray_end - ray_begin;
+    const int chunk = ctx->opt_chunk > 0 && ctx->opt_chunk < nrays ? ctx->opt_chunk : nrays;
+    const int nchunks = (nrays + chunk - 1) / chunk;
+    const unsigned long long nitems = (unsigned long long)u->tileWidth * u->tileHeight * nchunks;
+    if (nitems > 0xF0000000ull) return fail(ctx, RT_ERR_TOO_LARGE, "rt: too many work items; raise RT_OPT_CHUNK");
+    RT_TRY(grow(ctx, ctx->planes, (size_t)nchunks * ctx->width * ctx->height));
+
+    TraceParams P;
+    fill_params(ctx, u, P);
+    P.tileX = u->tileX; P.tileY = u->tileY; P.tileW = u->tileWidth; P.tileH = u->tileHeight;
+    P.ray_begin = ray_begin;
+    P.ray_end = ray_end;
+    P.chunk = chunk;
+    P.nitems = (uint32_t)nitems;
+    P.mode = kModeAccum;
+    P.planes = ctx->planes.ptr;
+    RT_TRY(enqueue_trace(ctx, P));
+    ctx->last.samples = (uint64_t)u->tileWidth * u->tileHeight * (uint64_t)nrays;
+    float4 *acc = accum_dev ? (float4 *)accum_dev : ctx->accum.ptr;
+    RT_HIP(launch_fold(acc, ctx->planes.ptr, nchunks, ctx->width, ctx->height, P.tileX, P.tileY, P.tileW, P.tileH,
+                       ctx->stream));
+    return RT_OK;
+}
+
+RT_API int rt_accum_clear(rt_ctx *ctx, float *accum_dev) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->target.ptr) return fail(ctx, RT_ERR_NO_TARGET, "rt: no render target");
+    Bind bind(ctx);
+    float4 *acc = accum_dev ? (float4 *)accum_dev : ctx->accum.ptr;
+    RT_HIP(hipMemsetAsync(acc, 0, (size_t)ctx->width * ctx->height * sizeof(float4), ctx->stream));
+    return RT_OK;
+}
+
+RT_API int rt_accum_ptr(rt_ctx *ctx, float **accum_dev) {
+    if (!ctx || !accum_dev) return RT_ERR_INVALID;
+    if (!ctx->accum.ptr) return fail(ctx, RT_ERR_NO_TARGET, "rt: no render target");
+    *accum_dev = (float *)ctx->accum.ptr;
+    return RT_OK;
+}
+
+RT_API int rt_resolve(rt_ctx *ctx, const float *accum_dev, int spp) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->target.ptr) return fail(ctx, RT_ERR_NO_TARGET, "rt: no render target");
+    Bind bind(ctx);
+    const float4 *acc = accum_dev ? (const float4 *)accum_dev : ctx->accum.ptr;
+    RT_HIP(launch_resolve(ctx->target.ptr, acc, ctx->width * ctx->height, spp, ctx->stream));
+    return RT_OK;
+}
+
+RT_API int rt_synchronize(rt_ctx *ctx) {
+    if (!ctx) return RT_ERR_INVALID;
+    Bind bind(ctx);
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+RT_API int rt_first_hit(rt_ctx *ctx, const Uniforms *u, const Object *objs, int objCount, float *out4, int32_t *ids) {
+    if (!ctx || !u || !out4 || !ids) return RT_ERR_INVALID;
+    if (!ctx->target.ptr) return fail(ctx, RT_ERR_NO_TARGET, "rt: no render target");
+    Bind bind(ctx);
+    RT_TRY(scene_for_call(ctx, u, objs, objCount));
+    TraceParams P;
+    fill_params(ctx, u, P);
+    size_t n = (size_t)ctx->width * ctx->height;
+    float4 *d4 = nullptr;
+    int *dids = nullptr;
+    RT_HIP(hipMalloc((void **)&d4, n * sizeof(float4)));
+    hipError_t e = hipMalloc((void **)&dids, n * sizeof(int));
+    if (e == hipSuccess) e = launch_first_hit(P, ctx->opt_arith != 0, d4, dids, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out4, d4, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ids, dids, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d4);
+    (void)hipFree(dids);
+    if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_first_hit", e);
+    return RT_OK;
+}
+
+RT_API int rt_last_stats(rt_ctx *ctx, rt_stats *out) {
+    if (!ctx || !out) return RT_ERR_INVALID;
+    Bind bind(ctx);
+    if (ctx->stats_pending) {
+        RT_HIP(hipStreamSynchronize(ctx->stream));
+        float ms = 0.0f;
+        RT_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        uint32_t host[4] = {0, 0, 0, 0};
+        RT_HIP(hipMemcpyAsync(host, ctx->counters, sizeof host, hipMemcpyDeviceToHost, ctx->stream));
+        RT_HIP(hipStreamSynchronize(ctx->stream));
+        uint64_t seg = (uint64_t)host[2] | ((uint64_t)host[3] << 32);
+        ctx->last.kernel_ms = ms;
+        ctx->last.segments = seg;
+        ctx->last.tests = seg * (uint64_t)ctx->nobj;
+        ctx->stats_pending = false;
+    }
+    *out = ctx->last;
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,261 @@
+// rt_device.hpp -- device-side building blocks of the path tracer for gfx950.
+//
+// Arithmetic contract: every float operation below is a single IEEE binary32
+// operation in the written order.  This file is compiled with -ffp-contract=off;
+// division and square root are hipcc's correctly rounded forms.  The only fused
+// multiply-adds are the explicit __builtin_fmaf calls of the FAST discriminant.
+// Metal built-ins are taken at their Metal Shading Language specification
+// formulas (dot = x*x'+y*y'+z*z' left to right, normalize = v / sqrt(dot(v,v)),
+// reflect = I - 2*dot(N,I)*N, refract with k = 1 - eta*eta*(1 - dot(N,I)^2),
+// fract = min(x - floor(x), 0x1.fffffep-1f), clamp = min(max(x,lo),hi)).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RT_DEV __device__ __forceinline__
+
+namespace rt {
+
+typedef float f4v __attribute__((ext_vector_type(4)));  // one compact sphere record, 16 bytes
+
+struct V3 { float x, y, z; };
+struct V4 { float x, y, z, w; };
+
+RT_DEV V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_DEV V4 v4(float x, float y, float z, float w) { V4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+RT_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_DEV V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+RT_DEV V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+RT_DEV V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+RT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_DEV float length(V3 a) { return __builtin_sqrtf(dot(a, a)); }
+RT_DEV V3 normalize(V3 a) { return a / length(a); }
+RT_DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+RT_DEV float fract(float x) { return __builtin_fminf(x - __builtin_floorf(x), 0x1.fffffep-1f); }
+RT_DEV float clampf(float x, float lo, float hi) { return __builtin_fminf(__builtin_fmaxf(x, lo), hi); }
+RT_DEV V3 reflect(V3 i, V3 n) { return i - (2.0f * dot(n, i)) * n; }
+RT_DEV V3 refract(V3 i, V3 n, float eta) {
+    float d = dot(n, i);
+    float k = 1.0f - eta * eta * (1.0f - d * d);
+    if (k < 0.0f) return v3(0.0f, 0.0f, 0.0f);
+    return eta * i - (eta * d + __builtin_sqrtf(k)) * n;
+}
+RT_DEV V4 operator+(V4 a, V4 b) { return v4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+RT_DEV V4 operator*(V4 a, V4 b) { return v4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+
+constexpr float kTMin = 0.001f;              // Shaders.metal:39
+constexpr float kMaxFloat = 3.402823466e+38f; // MAXFLOAT
+
+// ---- RNG (Lib.metal:59-72) -------------------------------------------------
+RT_DEV uint32_t pcg_hash(uint32_t input) {
+    uint32_t state = input * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+
+struct Seed { float x, y; };
+
+RT_DEV float random_double(Seed &seed) {
+    uint32_t ix = (uint32_t)(seed.x * 65536.0f);
+    uint32_t iy = (uint32_t)(seed.y * 65536.0f);
+    uint32_t hash = pcg_hash(ix ^ pcg_hash(iy));
+    seed.x = fract(seed.x + 0.618034f);
+    seed.y = fract(seed.y + 0.381966f);
+    return (float)hash / 4294967296.0f;
+}
+
+// Lib.metal:117-132
+RT_DEV V3 random_unit_vec(Seed &seed) {
+    float x1, x2, w;
+    do {
+        x1 = 2.0f * random_double(seed) - 1.0f;
+        x2 = 2.0f * random_double(seed) - 1.0f;
+        w = x1 * x1 + x2 * x2;
+    } while (w >= 1.0f);
+    float multiplier = 2.0f * __builtin_sqrtf(1.0f - w);
+    return v3(x1 * multiplier, x2 * multiplier, 1.0f - 2.0f * w);
+}
+
+// Shaders.metal:121-126
+RT_DEV Seed sample_seed(uint32_t px, uint32_t py, int currentSample, int rayIndex) {
+    Seed s;
+    s.x = (float)(px * 1973u + py * 9277u + (uint32_t)(currentSample * 26699) + (uint32_t)(rayIndex * 7919)) / 65536.0f;
+    s.y = (float)(py * 4513u + px * 6389u + (uint32_t)(currentSample * 30103) + (uint32_t)(rayIndex * 8191)) / 65536.0f;
+    s.x = fract(s.x + 0.618034f);
+    s.y = fract(s.y + 0.381966f);
+    return s;
+}
+
+// Camera part of Uniforms (Definitions.h:17-26), unpacked.
+struct Camera {
+    V3 pixelOrigin, pixelDeltaX, pixelDeltaY, cameraCenter, defocusDiskU, defocusDiskV;
+    float defocusAngle;
+};
+
+// Lib.metal:99-106 with random_square (:78-82), defocusDiskSample (:94-97), random_in_unit_disk (:84-92).
+RT_DEV void get_ray(int i, int j, const Camera &cam, Seed &seed, V3 &dir, V3 &origin) {
+    float ox = random_double(seed) - 0.5f;
+    float oy = random_double(seed) - 0.5f;
+    V3 pixel_sample = cam.pixelOrigin + (((float)i + ox) * cam.pixelDeltaX) + (((float)j + oy) * cam.pixelDeltaY);
+    V3 ray_origin;
+    if (cam.defocusAngle <= 0.0f) {
+        ray_origin = cam.cameraCenter;
+    } else {
+        float x, y;
+        do {
+            x = 2.0f * random_double(seed) - 1.0f;
+            y = 2.0f * random_double(seed) - 1.0f;
+        } while (x * x + y * y >= 1.0f);
+        ray_origin = cam.cameraCenter + (x * cam.defocusDiskU) + (y * cam.defocusDiskV);
+    }
+    dir = normalize(pixel_sample - ray_origin);
+    origin = ray_origin;
+}
+
+// ---- compact scene --------------------------------------------------------
+// Per object, in the object's original index order.
+struct MatDev {
+    V4 albedo;
+    V4 emis;       // emission > 0 ? emission_color * emission : (0,0,0,1)   (Shaders.metal:51-54)
+    int type;      // LAMBIERTIAN 0 / REFLECTEE 1 / DIELECTRIC 2, anything else absorbs (Lib.metal:203-213)
+    float fuzz;
+    float ior;
+    float inv_ior; // 1.0f / ior (Lib.metal:185)
+};
+// Per quad: geometry as given plus the object index.
+struct QuadDev {
+    V3 origin; int obj;
+    V3 ex; float pad0;
+    V3 ey; float pad1;
+};
+
+struct Hit {
+    V3 point, normal;
+    bool front;
+};
+
+// Lib.metal:53-56
+RT_DEV void apply_normals(Hit &h, V3 dir, V3 outward) {
+    h.front = dot(dir, outward) < 0.0f;
+    h.normal = h.front ? outward : -outward;
+}
+
+// Sphere discriminant of Lib.metal:216-221 from the compact record s = (cx, cy, cz, r*r).
+template <bool FAST>
+RT_DEV float sphere_disc(f4v s, V3 o, V3 d, float a, float &b_out) {
+    float ocx = o.x - s.x, ocy = o.y - s.y, ocz = o.z - s.z;
+    if constexpr (FAST) {
+        float b = __builtin_fmaf(ocz, d.z, __builtin_fmaf(ocy, d.y, ocx * d.x));
+        float c = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx)) - s.w;
+        b_out = b;
+        return __builtin_fmaf(b, b, -(a * c));
+    } else {
+        float b = ocx * d.x + ocy * d.y + ocz * d.z;
+        float c = (ocx * ocx + ocy * ocy + ocz * ocz) - s.w;
+        b_out = b;
+        return b * b - a * c;
+    }
+}
+
+// Root selection of Lib.metal:230-238 against the interval (kTMin, tmax).  Returns true and the root.
+RT_DEV bool sphere_root(float disc, float b, float a, float tmax, float &root_out) {
+    if (disc < 0.0f) return false;
+    float sqrtd = __builtin_sqrtf(disc);
+    float root = (-b - sqrtd) / a;
+    if (!(kTMin < root && root < tmax)) {
+        root = (-b + sqrtd) / a;
+        if (!(kTMin < root && root < tmax)) return false;
+    }
+    root_out = root;
+    return true;
+}
+
+// Lib.metal:248-280.  Interval is [kTMin, tmax] inclusive (Interval::contains).
+RT_DEV bool hit_quad(const QuadDev &q, V3 o, V3 d, float tmax, float &t_out, V3 &point, V3 &normal_out) {
+    V3 n = cross(q.ex, q.ey);
+    V3 normal = normalize(n);
+    float denom = dot(normal, d);
+    if (__builtin_fabsf(denom) < 1e-8f) return false;
+    float t = dot(normal, q.origin - o) / denom;
+    if (!(kTMin <= t && t <= tmax)) return false;
+    V3 inter = o + t * d;
+    V3 toPoint = inter - q.origin;
+    float dotU = dot(toPoint, normalize(q.ex));
+    float dotV = dot(toPoint, normalize(q.ey));
+    float uLen = length(q.ex);
+    float vLen = length(q.ey);
+    if (dotU < 0.0f || dotU > uLen || dotV < 0.0f || dotV > vLen) return false;
+    t_out = t;
+    point = inter;
+    normal_out = normal;
+    return true;
+}
+
+// pow(1 - cosine, 5) of Lib.metal:180, evaluated as a product in binary64 and rounded once:
+// within 2^-50 relative of the exact power before the final rounding.
+RT_DEV float pow5(float x) {
+    double p = (double)x;
+    double p2 = p * p;
+    return (float)(p2 * p2 * p);
+}
+
+// Lib.metal:177-181
+RT_DEV float reflectance(float cosine, float refraction_index) {
+    float r0 = (1.0f - refraction_index) / (1.0f + refraction_index);
+    r0 = r0 * r0;
+    return r0 + (1.0f - r0) * pow5(1.0f - cosine);
+}
+
+// materialScatters (Lib.metal:157-213).  On return true: attenuation, new ray (dir, origin).
+// Lambertian keeps the reference's field order: the scattered ray's DIRECTION is the hit point and its
+// ORIGIN is normal + random unit vector (Lib.metal:164 initialises Ray{direction, origin} positionally).
+RT_DEV bool scatter(const MatDev &m, V3 &dir, V3 &origin, const Hit &hit, V4 &attenuation, Seed &seed) {
+    if (m.type == 0) {
+        V3 scatter_direction = hit.normal + random_unit_vec(seed);
+        const float s = 1e-8f;
+        if ((__builtin_fabsf(scatter_direction.x) < s) && (__builtin_fabsf(scatter_direction.y) < s) &&
+            (__builtin_fabsf(scatter_direction.z) < s))
+            scatter_direction = hit.normal;
+        dir = hit.point;
+        origin = scatter_direction;
+        attenuation = m.albedo;
+        return true;
+    } else if (m.type == 1) {
+        V3 reflected = reflect(dir, hit.normal);
+        reflected = normalize(reflected) + (m.fuzz * random_unit_vec(seed));
+        dir = normalize(reflected);
+        origin = hit.point;
+        attenuation = m.albedo;
+        return dot(dir, hit.normal) > 0.0f;
+    } else if (m.type == 2) {
+        attenuation = v4(1.0f, 1.0f, 1.0f, 1.0f);
+        float ri = hit.front ? m.inv_ior : m.ior;
+        V3 unit_dir = normalize(dir);
+        float cos_theta = __builtin_fminf(dot(-unit_dir, hit.normal), 1.0f);
+        float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+        bool cannot_refract = ri * sin_theta > 1.0f;
+        V3 direction;
+        if (cannot_refract || reflectance(cos_theta, ri) > random_double(seed)) {
+            direction = reflect(unit_dir, hit.normal);
+        } else {
+            direction = refract(unit_dir, hit.normal, ri);
+        }
+        dir = direction;
+        origin = hit.point;
+        return true;
+    }
+    return false;
+}
+
+// write_color (Shaders.metal:71-85) + linear_to_gamma (Lib.metal:144-150).
+RT_DEV float gamma_channel(float c, float nan_value) {
+    float v = clampf(__builtin_isnan(c) ? nan_value : c, 0.0f, 1.0f);
+    return v > 0.0f ? __builtin_sqrtf(v) : 0.0f;
+}
+RT_DEV V4 write_color(V4 c) {
+    return v4(gamma_channel(c.x, 0.0f), gamma_channel(c.y, 0.0f), gamma_channel(c.z, 0.0f), gamma_channel(c.w, 1.0f));
+}
+
+}  // namespace rt

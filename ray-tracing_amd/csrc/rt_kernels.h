@@ -1,0 +1,51 @@
+// rt_kernels.h -- kernel parameter block and launcher declarations shared by rt_kernels.hip and rt_api.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_device.hpp"
+
+namespace rt {
+
+enum { kModeAccum = 0, kModeProgressive = 1 };
+
+// Everything one trace launch needs.  Passed by value in the kernel argument segment.
+struct TraceParams {
+    Camera cam;
+    V4 sky;                 // Uniforms.globalIllumation
+    const float4 *sph;      // [nsph_pad] (cx, cy, cz, r*r); padding records have r*r = -inf and never hit
+    const float *rad;       // [nsph_pad] radius
+    const int *sph_obj;     // [nsph_pad] object index of each sphere slot
+    const QuadDev *quads;   // [nquad]
+    const MatDev *mats;     // [nobj] indexed by object index
+    int nsph, nsph_pad, nquad, nobj;
+    int width, height;      // render target size
+    int tileX, tileY, tileW, tileH;
+    int pass;               // Uniforms.currentSample
+    int maxDepth;           // Uniforms.maxRayDepth
+    int ray_begin, ray_end; // rayIndex range traced by this launch
+    int chunk;              // samples per work item
+    uint32_t nitems;        // tileW * tileH * ceil((ray_end - ray_begin) / chunk)
+    uint32_t *counter;      // work-item counter, zeroed before the launch
+    unsigned long long *seg_counter;  // += number of closest-hit searches
+    float4 *planes;         // kModeAccum: [nchunks][width*height] partial sums, one plane per chunk
+    float4 *target;         // kModeProgressive: rgba32Float render target
+    int mode;
+    int spp_pass;           // kModeProgressive: Uniforms.sampleCount
+};
+
+hipError_t launch_trace(const TraceParams &P, bool fast, bool lds_scene, int blocks, hipStream_t stream);
+int trace_blocks_per_cu(bool fast, bool lds_scene, size_t lds_bytes);
+hipError_t launch_fold(float4 *accum, const float4 *planes, int nplanes, int width, int height, int tileX, int tileY,
+                       int tileW, int tileH, hipStream_t stream);
+hipError_t launch_resolve(float4 *target, const float4 *accum, int npix, int spp, hipStream_t stream);
+hipError_t launch_fill_rect(float4 *target, int width, int height, int x0, int y0, int w, int h, float4 value,
+                            hipStream_t stream);
+hipError_t launch_error_pixels(float4 *target, int width, int height, int gw, int gh, int tileX, int tileY, int tileW,
+                               int tileH, int all_fail, hipStream_t stream);
+hipError_t launch_present_bgra8(const float4 *target, int width, int height, uint32_t *out, int out_w, int out_h,
+                                hipStream_t stream);
+hipError_t launch_first_hit(const TraceParams &P, bool fast, float4 *out4, int *ids, hipStream_t stream);
+
+}  // namespace rt
