@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-tracing hot path on MI355X.
+
+One step = one full render of the workload: clear the linear accumulation buffer, trace every sample of every
+pixel (each rank its share of the sample indices), reduce the ranks' float4 accumulation buffers to rank 0
+over RCCL (N > 1 only), and run the gamma/present resolve.  Scene, camera and buffers are resident in HBM
+before the timed region.  Prints ONE JSON line on rank 0.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X FP32 vector peak (256 CUs x 256 flop/clk x 2.4 GHz)
+FLOPS_PER_TEST = 23            # one ray-sphere test as the reference writes it, up to the discriminant early-out
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--scene", default="cover")
+    p.add_argument("--width", type=int, default=1920)
+    p.add_argument("--height", type=int, default=1080)
+    p.add_argument("--spp", type=int, default=1000)
+    p.add_argument("--depth", type=int, default=50)
+    p.add_argument("--chunk", type=int, default=-1, help="samples per work item (-1 = library default)")
+    p.add_argument("--arith", type=int, default=0, help="0 strict (bit-identical to the oracle), 1 fused discriminant")
+    p.add_argument("--fetch", type=int, default=0, help="0 spheres in LDS, 1 scalar cache")
+    p.add_argument("--blocks-per-cu", type=int, default=0)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-spp", type=int, default=64, help="spp of the sub-sampled CPU baseline run")
+    p.add_argument("--cpu-stride", type=int, default=4, help="pixel stride of the sub-sampled CPU baseline run")
+    return p.parse_args()
+
+
+def cpu_baseline(rt, ge, args):
+    """The oracle (a plain-C port of the reference's kernel) on the host cores, on a stratified sub-sample of the
+    same workload: every `stride`-th pixel in x and y at `cpu_spp` samples per pixel."""
+    ora = ge.load_oracle()
+    ora.rto_dispatch.restype = None
+    ora.rto_dispatch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    import numpy as np
+    objs, n = rt.scene(args.scene)
+    u = rt.config_uniforms(args.scene, args.width, args.height, args.cpu_spp, args.depth, n)
+    tex = np.zeros((args.height, args.width, 4), np.float32)
+    t0 = time.perf_counter()
+    ora.rto_dispatch(tex.ctypes.data, args.width, args.height, C.byref(u), objs, 0, args.cpu_stride, None)
+    dt = time.perf_counter() - t0
+    npx = len(range(0, args.width, args.cpu_stride)) * len(range(0, args.height, args.cpu_stride))
+    samples = npx * args.cpu_spp
+    return {
+        "value": samples / dt * 1e-6,
+        "unit": "Msamples*px/s",
+        "cores": int(ora.rto_num_threads()),
+        "kind": "port",
+        "sample": "every %dth pixel in x and y of the %dx%d %s frame at %d spp, depth %d (%d samples, %.1f s)"
+                  % (args.cpu_stride, args.width, args.height, args.scene, args.cpu_spp, args.depth, samples, dt),
+    }
+
+
+def main():
+    args = parse()
+    import torch  # before the HIP library, so both share one HIP runtime
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+    rt = ge.load_package()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rt_partition", os.path.join(ROOT, "ray-tracing_amd", "partition.py"))
+    part = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(part)
+
+    W, H, spp = args.width, args.height, args.spp
+    stream = torch.cuda.current_stream()
+    r = rt.MetalRenderer(device=local_rank, stream=stream.cuda_stream)
+    r.setupTexture(W, H)
+    if args.chunk >= 0:
+        r.set_option(rt.RT_OPT_CHUNK, args.chunk)
+    r.set_option(rt.RT_OPT_ARITH, args.arith)
+    r.set_option(rt.RT_OPT_SCENE_FETCH, args.fetch)
+    r.set_option(rt.RT_OPT_BLOCKS_PER_CU, args.blocks_per_cu)
+    objs, n = rt.scene(args.scene)
+    u = rt.config_uniforms(args.scene, W, H, spp, args.depth, n)
+    r.setScene(objs, n)  # resident before the timed region
+    accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    begin, end = part.ray_range(rank, world, spp)
+
+    def step():
+        r.accumClear(accum.data_ptr())
+        r.render(u, None, 0, begin, end, accum.data_ptr())
+        if world > 1:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            r.resolve(spp, accum.data_ptr())
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    r.traceTimes()  # drop the warm-up launches
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    trace_ms = r.traceTimes()
+    st = r.lastStats()
+    out = None
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        total_samples = W * H * spp
+        avg_trace_ms = sum(trace_ms) / max(1, len(trace_ms))
+        flops_per_launch = FLOPS_PER_TEST * st.tests
+        achieved = flops_per_launch / (avg_trace_ms * 1e-3) * 1e-12 if avg_trace_ms > 0 else 0.0
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_trace_hbm_bytes.json")
+        if world == 1 and os.path.exists(pmc_path):
+            try:
+                rec = json.load(open(pmc_path))
+                if rec.get("workload") == "%s %dx%d %dspp" % (args.scene, W, H, spp):
+                    traffic = rec.get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Msamples*px/s (whole job), RTiOW cover 1080p; % FP32 VALU peak",
+            "value": total_samples / (ms_per_step * 1e-3) * 1e-6,
+            "unit": "Msamples*px/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (generated %s scene, fixed seed; random-free camera)" % args.scene,
+            "config": {
+                "workload": "%s scene (%d spheres) %dx%d, %d spp, depth %d, one pass" % (args.scene, n, W, H, spp, args.depth),
+                "arithmetic": "strict" if args.arith == 0 else "fused-discriminant",
+                "samples_per_rank": end - begin,
+                "parallelism": "sample-index split x%d, RCCL reduce of float4 accumulation buffers" % world,
+            },
+            "roofline": {
+                "bound": "valu_fp32",
+                "achieved": achieved,
+                "peak": FP32_VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / FP32_VALU_PEAK_TFLOPS,
+                "traffic": traffic,
+                "kernel": "trace_kernel (rank 0)",
+                "flops_per_launch": flops_per_launch,
+                "avg_launch_ms": avg_trace_ms,
+                "segments_per_sample": st.segments / max(1, st.samples),
+                "pct_valu_peak_whole_job": 100.0 * FLOPS_PER_TEST * st.tests * world / (ms_per_step * 1e-3) * 1e-12
+                                           / (FP32_VALU_PEAK_TFLOPS * world),
+            },
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(rt, ge, args)
+        print(json.dumps(out), flush=True)
+    r.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -133,6 +133,11 @@ struct rt_stats {
 };
 RT_API int rt_last_stats(rt_ctx *ctx, struct rt_stats *out);
 
+/* Device durations (ms, HIP events on the context's stream) of the trace launches enqueued since the
+ * previous call of this function, oldest first; at most the 64 most recent are kept.  Writes up to `cap`
+ * values and stores the number written in *count.  Blocks until those launches have finished. */
+RT_API int rt_trace_times(rt_ctx *ctx, float *ms, int cap, int *count);
+
 #ifdef __cplusplus
 }
 #endif

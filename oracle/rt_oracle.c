@@ -457,6 +457,14 @@ static void computeShader(const Texture *outputTexture, const Uniforms *uniforms
 /* Exported test surface                                                     */
 /* ======================================================================== */
 
+#ifdef _OPENMP
+#include <omp.h>
+/* Number of threads the OpenMP loops below will use. */
+RTO_API int rto_num_threads(void) { return omp_get_max_threads(); }
+#else
+RTO_API int rto_num_threads(void) { return 1; }
+#endif
+
 RTO_API uint32_t rto_pcg_hash(uint32_t x) { return pcg_hash(x); }
 
 RTO_API float rto_random_double(float seed[2]) {

@@ -89,7 +89,7 @@ RT_OPT_CHUNK, RT_OPT_ARITH, RT_OPT_KERNEL, RT_OPT_SCENE_FETCH, RT_OPT_BLOCKS_PER
 AMD_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_option", "rt_get_option", "rt_set_target", "rt_clear",
     "rt_write_target", "rt_read_target", "rt_render_tile", "rt_present_bgra8", "rt_set_scene", "rt_render",
-    "rt_accum_clear", "rt_accum_ptr", "rt_resolve", "rt_synchronize", "rt_first_hit", "rt_last_stats",
+    "rt_accum_clear", "rt_accum_ptr", "rt_resolve", "rt_synchronize", "rt_first_hit", "rt_last_stats", "rt_trace_times",
 ]
 HOST_SYMBOLS = [
     "rt_material_default", "rt_material_lambertian", "rt_material_metal", "rt_material_dielectric", "rt_material_light",
@@ -129,6 +129,7 @@ def amd_lib():
         lib.rt_synchronize.argtypes = [vp]
         lib.rt_first_hit.argtypes = [vp, C.POINTER(Uniforms), vp, ip, vp, vp]
         lib.rt_last_stats.argtypes = [vp, C.POINTER(Stats)]
+        lib.rt_trace_times.argtypes = [vp, vp, ip, C.POINTER(ip)]
         _amd = lib
     return _amd
 
@@ -422,6 +423,13 @@ class MetalRenderer:
         s = Stats()
         self._check(self._lib.rt_last_stats(self._ctx, C.byref(s)))
         return s
+
+    def traceTimes(self):
+        """Device durations (ms) of the trace launches since the previous call."""
+        buf = (C.c_float * 64)()
+        cnt = C.c_int()
+        self._check(self._lib.rt_trace_times(self._ctx, buf, 64, C.byref(cnt)))
+        return list(buf[:cnt.value])
 
     def renderImage(self, u, objs, n, chunk=None):
         """Whole image in one go: clear accumulation, trace u.sampleCount samples, resolve, read back."""

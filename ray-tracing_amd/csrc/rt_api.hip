@@ -44,7 +44,10 @@ struct rt_ctx {
     bool scene_resident = false;
 
     uint32_t *counters = nullptr;  // 256 B: [0] work counter (u32), [2..3] segment counter (u64)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    static constexpr int kRing = 64;
+    hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};
+    unsigned long long launches = 0;    // trace launches so far
+    unsigned long long times_read = 0;  // launches already reported by rt_trace_times
     bool stats_pending = false;
 
     int opt_chunk = 64;
@@ -233,9 +236,11 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
     RT_HIP(hipMemsetAsync(ctx->counters, 0, 256, ctx->stream));
-    RT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    const int slot = (int)(ctx->launches % rt_ctx::kRing);
+    RT_HIP(hipEventRecord(ctx->ev0[slot], ctx->stream));
     RT_HIP(launch_trace(P, fast, lds_scene, (int)blocks, ctx->stream));
-    RT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    RT_HIP(hipEventRecord(ctx->ev1[slot], ctx->stream));
+    ctx->launches++;
     ctx->stats_pending = true;
     ctx->last = {};
     ctx->last.grid_blocks = (int)blocks;
@@ -273,8 +278,10 @@ RT_API int rt_create(rt_ctx **out, int device, void *stream) {
         }
         ctx->own_stream = true;
     }
-    if (hipMalloc((void **)&ctx->counters, 256) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
-        hipEventCreate(&ctx->ev1) != hipSuccess) {
+    bool ok = hipMalloc((void **)&ctx->counters, 256) == hipSuccess;
+    for (int i = 0; ok && i < rt_ctx::kRing; ++i)
+        ok = hipEventCreate(&ctx->ev0[i]) == hipSuccess && hipEventCreate(&ctx->ev1[i]) == hipSuccess;
+    if (!ok) {
         rt_destroy(ctx);
         return RT_ERR_HIP;
     }
@@ -295,8 +302,10 @@ RT_API void rt_destroy(rt_ctx *ctx) {
     (void)hipFree(ctx->quads.ptr);
     (void)hipFree(ctx->mats.ptr);
     (void)hipFree(ctx->counters);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (int i = 0; i < rt_ctx::kRing; ++i) {
+        if (ctx->ev0[i]) (void)hipEventDestroy(ctx->ev0[i]);
+        if (ctx->ev1[i]) (void)hipEventDestroy(ctx->ev1[i]);
+    }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -547,7 +556,8 @@ RT_API int rt_last_stats(rt_ctx *ctx, rt_stats *out) {
     if (ctx->stats_pending) {
         RT_HIP(hipStreamSynchronize(ctx->stream));
         float ms = 0.0f;
-        RT_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        const int slot = (int)((ctx->launches - 1) % rt_ctx::kRing);
+        RT_HIP(hipEventElapsedTime(&ms, ctx->ev0[slot], ctx->ev1[slot]));
         uint32_t host[4] = {0, 0, 0, 0};
         RT_HIP(hipMemcpyAsync(host, ctx->counters, sizeof host, hipMemcpyDeviceToHost, ctx->stream));
         RT_HIP(hipStreamSynchronize(ctx->stream));
@@ -558,6 +568,22 @@ RT_API int rt_last_stats(rt_ctx *ctx, rt_stats *out) {
         ctx->stats_pending = false;
     }
     *out = ctx->last;
+    return RT_OK;
+}
+
+RT_API int rt_trace_times(rt_ctx *ctx, float *ms, int cap, int *count) {
+    if (!ctx || !ms || !count || cap < 0) return RT_ERR_INVALID;
+    Bind bind(ctx);
+    *count = 0;
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    unsigned long long first = ctx->times_read;
+    if (ctx->launches - first > (unsigned long long)rt_ctx::kRing) first = ctx->launches - rt_ctx::kRing;
+    for (unsigned long long i = first; i < ctx->launches && *count < cap; ++i) {
+        const int slot = (int)(i % rt_ctx::kRing);
+        RT_HIP(hipEventElapsedTime(&ms[*count], ctx->ev0[slot], ctx->ev1[slot]));
+        ++*count;
+    }
+    ctx->times_read = ctx->launches;
     return RT_OK;
 }
 

@@ -1,0 +1,293 @@
+"""GPU: the HIP path, called through the C-ABI, against the CPU oracle and the committed vectors.
+
+Bar (strict arithmetic, the default): bit-identical float images, exact first-hit object ids.
+Bar for RT_OPT_ARITH=1 (fused multiply-add in the discriminant): exact-or-better than the tolerance the
+task states for converged images, PSNR >= 45 dB against the oracle.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import bits, psnr
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = np.load(os.path.join(HERE, "golden", "oracle_vectors.npz"))
+
+
+def strict(r, rt, chunk=0, fetch=0):
+    r.set_option(rt.RT_OPT_ARITH, 0)
+    r.set_option(rt.RT_OPT_SCENE_FETCH, fetch)
+    r.set_option(rt.RT_OPT_CHUNK, chunk)
+    r.set_option(rt.RT_OPT_BLOCKS_PER_CU, 0)
+
+
+def test_committed_images_bit_exact(rt, renderer):
+    """No oracle call: GPU output against the vectors in tests/golden/."""
+    strict(renderer, rt)
+    for name in ("three_spheres", "cover", "cornell"):
+        w, h, spp, depth = [int(v) for v in GOLD["img_%s_cfg" % name]]
+        objs, n = rt.scene(name)
+        u = rt.config_uniforms(name, w, h, spp, depth, n)
+        renderer.setupTexture(w, h)
+        img = renderer.renderImage(u, objs, n)
+        assert np.array_equal(bits(img), bits(GOLD["img_%s" % name])), name
+        t4, ids = renderer.firstHit(u, objs, n)
+        assert np.array_equal(ids, GOLD["fh_%s_id" % name].astype(np.int32)), name
+        assert np.array_equal(bits(t4), bits(GOLD["fh_%s_t" % name])), name
+
+
+@pytest.mark.parametrize("name,w,h", [("three_spheres", 400, 225), ("cover", 400, 225), ("cornell", 250, 200)])
+def test_first_hit_buffers(rt, oracle, renderer, name, w, h):
+    """Exact object id; t and normal within 1e-5 relative (they are in fact bit-identical)."""
+    strict(renderer, rt)
+    objs, n = rt.scene(name)
+    u = rt.config_uniforms(name, w, h, 1, 50, n)
+    renderer.setupTexture(w, h)
+    t4, ids = renderer.firstHit(u, objs, n)
+    want4, want_ids = oracle.first_hit(u, objs, w, h)
+    assert np.array_equal(ids, want_ids)
+    np.testing.assert_allclose(t4, want4, rtol=1e-5, atol=0)
+    assert np.array_equal(bits(t4), bits(want4))
+    assert (ids >= 0).any() and len(np.unique(ids)) >= 3
+
+
+@pytest.mark.parametrize("fetch", [0, 1])
+def test_three_sphere_full_config_bit_exact(rt, oracle, renderer, fetch):
+    """The 400x225, 100 spp, depth 50 three-sphere configuration in full."""
+    strict(renderer, rt, fetch=fetch)
+    objs, n = rt.scene("three_spheres")
+    u = rt.config_uniforms("three_spheres", 400, 225, 100, 50, n)
+    renderer.setupTexture(400, 225)
+    img = renderer.renderImage(u, objs, n)
+    stats = [0] * 5
+    want = oracle.image(u, objs, 400, 225, stats=stats)
+    assert np.array_equal(bits(img), bits(want))
+    st = renderer.lastStats()
+    assert st.segments == stats[0] and st.tests == stats[1] and st.samples == 400 * 225 * 100
+
+
+@pytest.mark.parametrize("name,w,h,spp,depth", [("cover", 240, 135, 32, 50), ("cornell", 200, 160, 16, 10),
+                                                 ("nested_glass", 160, 90, 4, 100)])
+def test_images_bit_exact(rt, oracle, renderer, name, w, h, spp, depth):
+    strict(renderer, rt)
+    objs, n = rt.scene(name)
+    u = rt.config_uniforms(name, w, h, spp, depth, n)
+    renderer.setupTexture(w, h)
+    img = renderer.renderImage(u, objs, n)
+    want = oracle.image(u, objs, w, h)
+    assert np.array_equal(bits(img), bits(want))
+
+
+def test_scene_larger_than_lds_bit_exact(rt, oracle, renderer):
+    """5000 spheres exceed the LDS staging limit: the kernel reads them through the scalar cache."""
+    strict(renderer, rt)
+    objs, n = rt.scene("random_spheres", n=5000, extent=20.0)
+    u = rt.config_uniforms("random_spheres", 96, 54, 2, 50, n)
+    renderer.setupTexture(96, 54)
+    img = renderer.renderImage(u, objs, n)
+    assert np.array_equal(bits(img), bits(oracle.image(u, objs, 96, 54)))
+
+
+def test_chunked_work_items_sum_in_chunk_order(rt, oracle, renderer):
+    """With RT_OPT_CHUNK=c each pixel's samples are summed per chunk, then chunks are added in order."""
+    strict(renderer, rt, chunk=5)
+    w, h, spp = 120, 68, 16
+    objs, n = rt.scene("cover")
+    u = rt.config_uniforms("cover", w, h, spp, 50, n)
+    renderer.setupTexture(w, h)
+    img = renderer.renderImage(u, objs, n, chunk=5)
+    acc = np.zeros((h, w, 4), np.float32)
+    for b in range(0, spp, 5):
+        acc = acc + oracle.accumulate(u, objs, w, h, b, min(b + 5, spp))
+    assert np.array_equal(bits(img), bits(oracle.resolve(acc, spp)))
+    # and the result is within float-sum reordering distance of the reference's single sequential sum
+    np.testing.assert_allclose(img, oracle.image(u, objs, w, h), atol=2e-6)
+
+
+def test_sample_split_equals_one_call(rt, renderer):
+    """Two calls over [0,s/2) and [s/2,s) into one buffer == one call with chunk s/2 (same add order)."""
+    strict(renderer, rt, chunk=8)
+    w, h, spp = 320, 180, 16
+    objs, n = rt.scene("cover")
+    u = rt.config_uniforms("cover", w, h, spp, 50, n)
+    renderer.setupTexture(w, h)
+    one = renderer.renderImage(u, objs, n, chunk=8)
+    renderer.setScene(objs, n)
+    renderer.accumClear()
+    renderer.render(u, None, 0, 0, 8)
+    renderer.render(u, None, 0, 8, 16)
+    renderer.resolve(spp)
+    renderer.synchronize()
+    two = renderer.readTexture()
+    assert np.array_equal(bits(one), bits(two))
+
+
+def test_full_size_cover_spot_pixels(rt, oracle, renderer):
+    """1200x675 cover configuration: 160 scattered pixels' linear sums against the oracle, bit for bit,
+    plus run-to-run determinism of the whole frame."""
+    strict(renderer, rt)
+    w, h, spp = 1200, 675, 24
+    objs, n = rt.scene("cover")
+    u = rt.config_uniforms("cover", w, h, spp, 50, n)
+    renderer.setupTexture(w, h)
+    img1 = renderer.renderImage(u, objs, n)
+    img2 = renderer.renderImage(u, objs, n, chunk=0)
+    assert np.array_equal(bits(img1), bits(img2))
+    rng = np.random.RandomState(3)
+    for _ in range(160):
+        x, y = int(rng.randint(0, w)), int(rng.randint(0, h))
+        acc = np.zeros(4, np.float32)
+        for k in range(spp):
+            c = (C.c_float * 4)()
+            if oracle.lib.rto_sample(C.byref(u), objs, x, y, k, c, None):
+                acc = acc + np.array(list(c), np.float32)
+        want = oracle.resolve(acc.reshape(1, 1, 4), spp)[0, 0]
+        assert np.array_equal(bits(img1[y, x]), bits(want)), (x, y)
+    assert np.isfinite(img1).all() and img1.min() >= 0 and img1.max() <= 1 and (img1[..., 3] == 1).all()
+
+
+def test_4k_seed_rounding_spot_pixels(rt, oracle, renderer):
+    """At 3840x2160 the integer seed expression exceeds 2^24 and is rounded on conversion to float."""
+    strict(renderer, rt)
+    w, h, spp = 3840, 2160, 2
+    objs, n = rt.scene("three_spheres")
+    u = rt.config_uniforms("three_spheres", w, h, spp, 50, n)
+    u.currentSample = 999
+    renderer.setupTexture(w, h)
+    renderer.setScene(objs, n)
+    renderer.accumClear()
+    renderer.render(u, None, 0, 0, spp)
+    renderer.resolve(spp)
+    renderer.synchronize()
+    img = renderer.readTexture()
+    for x, y in [(3839, 2159), (3838, 2159), (0, 2159), (3839, 0), (2047, 1301), (1919, 1079)]:
+        acc = np.zeros(4, np.float32)
+        for k in range(spp):
+            c = (C.c_float * 4)()
+            if oracle.lib.rto_sample(C.byref(u), objs, x, y, k, c, None):
+                acc = acc + np.array(list(c), np.float32)
+        assert np.array_equal(bits(img[y, x]), bits(oracle.resolve(acc.reshape(1, 1, 4), spp)[0, 0])), (x, y)
+
+
+def test_progressive_tiles_match_reference_semantics(rt, oracle, renderer):
+    """The reference's own flow: 64x64 tiles, several passes, gamma-encoded running mean, and the yellow
+    pixels its 8x8 threadgroups paint for edge tiles whose size is not a multiple of 8."""
+    strict(renderer, rt)
+    w, h, passes = 100, 70, 3
+    objs, n = rt.scene("cornell")
+    renderer.setupTexture(w, h)
+    rt.initRayTracing(renderer, w, h)
+    renderer.uniforms.sampleCount = 4
+    renderer.uniforms.maxRayDepth = 6
+    renderer.objects = [objs[i] for i in range(n)]
+    renderer.maxIterations = passes
+    renderer.startProgressiveRender()
+    steps = 0
+    while renderer.renderTile():
+        steps += 1
+    assert steps == passes * (len(renderer.tiles) + 1) - 1 and len(renderer.tiles) == 4
+    got = renderer.readTexture()
+    tex = np.zeros((h, w, 4), np.float32)
+    tex[..., 3] = 1
+    for p in range(passes):
+        for t in renderer.tiles:
+            u = rt.Uniforms.from_buffer_copy(renderer.uniforms)
+            u.currentSample, u.totalSamples, u.objCount = p, passes, n
+            u.tileX, u.tileY, u.tileWidth, u.tileHeight = t.x, t.y, t.width, t.height
+            oracle.image(u, objs, w, h, tex=tex, reference_grid=1)
+    assert np.array_equal(bits(got), bits(tex))
+    yellow = np.array([1, 1, 0, 1], np.float32)
+    assert (got[..., :] == yellow).all(axis=-1).any()  # 36x6 edge tiles: threads 36..39 / 6..7 paint yellow
+    # present pass
+    assert np.array_equal(renderer.present(), oracle.present(got, w, h))
+    assert np.array_equal(renderer.present(2 * w, 2 * h), oracle.present(got, 2 * w, 2 * h))
+
+
+def test_current_sample_above_10000_paints_yellow(rt, oracle, renderer):
+    strict(renderer, rt)
+    w, h = 64, 48
+    objs, n = rt.scene("three_spheres")
+    renderer.setupTexture(w, h)
+    u = rt.config_uniforms("three_spheres", w, h, 2, 5, n)
+    u.currentSample = 10001
+    u.tileX, u.tileY, u.tileWidth, u.tileHeight = 16, 8, 20, 12
+    rc = rt.amd_lib().rt_render_tile(renderer._ctx, C.byref(u), objs, n)
+    assert rc == 1
+    got = renderer.readTexture()
+    want = np.zeros((h, w, 4), np.float32)
+    want[..., 3] = 1
+    oracle.image(u, objs, w, h, tex=want, reference_grid=1)
+    assert np.array_equal(bits(got), bits(want))
+    assert (got[0:16, 0:24] == np.array([1, 1, 0, 1], np.float32)).all()
+
+
+def test_degenerate_inputs(rt, oracle, renderer):
+    strict(renderer, rt)
+    w, h = 40, 24
+    objs, n = rt.scene("three_spheres")
+    renderer.setupTexture(w, h)
+    # empty scene: every ray misses -> sky
+    u = rt.config_uniforms("three_spheres", w, h, 3, 5, 0)
+    img = renderer.renderImage(u, objs, n)
+    assert np.array_equal(bits(img), bits(oracle.image(u, objs, w, h)))
+    # zero samples per pass: 0/0 -> NaN -> scrubbed to (0,0,0,1), on both the first and a later pass
+    u = rt.config_uniforms("three_spheres", w, h, 0, 5, n)
+    tex = np.zeros((h, w, 4), np.float32)
+    tex[..., 3] = 1
+    for p in (0, 1):
+        u.currentSample = p
+        assert rt.amd_lib().rt_render_tile(renderer._ctx, C.byref(u), objs, n) == 0
+        oracle.image(u, objs, w, h, tex=tex)
+        assert np.array_equal(bits(renderer.readTexture()), bits(tex))
+    # depth 0: color_ray's loop never runs -> black with alpha 0 -> stored as (0,0,0,0)
+    u = rt.config_uniforms("three_spheres", w, h, 2, 0, n)
+    img = renderer.renderImage(u, objs, n)
+    assert np.array_equal(bits(img), bits(oracle.image(u, objs, w, h)))
+    # unknown material type absorbs; unknown object type never hits
+    objs2 = (rt.Object * n)(*[objs[i] for i in range(n)])
+    objs2[1].mat.type = 7
+    objs2[4].type = 5
+    u = rt.config_uniforms("three_spheres", w, h, 4, 20, n)
+    img = renderer.renderImage(u, objs2, n)
+    assert np.array_equal(bits(img), bits(oracle.image(u, objs2, w, h)))
+
+
+def test_error_codes(rt):
+    r = rt.MetalRenderer(0)
+    objs, n = rt.scene("three_spheres")
+    u = rt.config_uniforms("three_spheres", 32, 32, 1, 5, n)
+    lib = rt.amd_lib()
+    assert lib.rt_render_tile(r._ctx, C.byref(u), objs, n) == -4           # no target yet
+    r.setupTexture(32, 32)
+    assert lib.rt_render(r._ctx, C.byref(u), None, 0, 0, 1, None) == -5      # no resident scene
+    u.tileWidth = 0
+    assert lib.rt_render_tile(r._ctx, C.byref(u), objs, n) == -1
+    u.tileWidth = 64
+    assert lib.rt_render(r._ctx, C.byref(u), objs, n, 0, 1, None) == -1      # batch tile must lie inside
+    assert lib.rt_set_target(r._ctx, 0, 5) == -1
+    assert lib.rt_set_option(r._ctx, 99, 0) == -1
+    assert b"rt" in lib.rt_last_error(r._ctx)
+    r.close()
+
+
+def test_fused_discriminant_mode_meets_psnr_bar(rt, oracle, renderer):
+    """RT_OPT_ARITH=1 is not bit-exact (different roundings flip a few hit decisions); it must still clear the
+    45 dB bar for converged images and keep first-hit ids equal on all but grazing pixels."""
+    w, h, spp = 240, 135, 32
+    objs, n = rt.scene("cover")
+    u = rt.config_uniforms("cover", w, h, spp, 50, n)
+    renderer.setupTexture(w, h)
+    renderer.set_option(rt.RT_OPT_ARITH, 1)
+    try:
+        img = renderer.renderImage(u, objs, n, chunk=0)
+        _, ids = renderer.firstHit(u, objs, n)
+    finally:
+        renderer.set_option(rt.RT_OPT_ARITH, 0)
+    want = oracle.image(u, objs, w, h)
+    assert psnr(img, want) >= 45.0
+    _, want_ids = oracle.first_hit(u, objs, w, h)
+    assert (ids != want_ids).mean() < 1e-3

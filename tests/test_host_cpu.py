@@ -1,0 +1,142 @@
+"""CPU: ABI layouts, exported symbols, the plain-C host driver (camera, scenes, tiles) and the partition logic."""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = np.load(os.path.join(HERE, "golden", "oracle_vectors.npz"))
+
+
+def test_abi_layout_matches_reference_header(rt):
+    """Sizes/offsets of Definitions.h:13-78 as Metal and Swift see them."""
+    U, O, M = rt.Uniforms, rt.Object, rt.MeshMaterial
+    assert C.sizeof(U) == 224
+    want = dict(color=0, time=16, pixelDeltaX=32, pixelDeltaY=48, pixelOrigin=64, pixelSampleScale=80, cameraCenter=96,
+                viewportSize=112, defocusDiskU=128, defocusDiskV=144, defocusAngle=160, objCount=164, lightCount=168,
+                sampleCount=172, maxRayDepth=176, currentSample=180, totalSamples=184, tileX=188, tileY=192, tileWidth=196,
+                tileHeight=200, globalIllumation=208)
+    for k, v in want.items():
+        assert getattr(U, k).offset == v, k
+    assert C.sizeof(rt.Sphere) == 32 and rt.Sphere.radius.offset == 16
+    assert C.sizeof(rt.Quad) == 48 and rt.Quad.extentX.offset == 16 and rt.Quad.extentY.offset == 32
+    assert C.sizeof(M) == 64 and M.emission.offset == 4 and M.albedo.offset == 16 and M.emission_color.offset == 32
+    assert M.reflection_fuzz.offset == 48 and M.refraction_index.offset == 52
+    assert C.sizeof(O) == 160 and O.s.offset == 16 and O.q.offset == 48 and O.mat.offset == 96
+
+
+def test_c_header_compiles_as_c_and_cpp():
+    """include/*.h carry the same contract as static assertions; they must compile stand-alone in C and C++."""
+    src = '#include "rt_amd.h"\nint main(void){return (int)sizeof(struct Object) - 160;}\n'
+    for cc, lang in (("gcc", "c"), ("g++", "c++")):
+        subprocess.run([cc, "-x", lang, "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-"], input=src.encode(), check=True)
+
+
+def test_libraries_export_every_declared_symbol(rt):
+    amd, host = rt.amd_lib(), rt.host_lib()
+    for s in rt.AMD_SYMBOLS:
+        assert hasattr(amd, s), s
+    for s in rt.HOST_SYMBOLS:
+        assert hasattr(host, s), s
+    # every RT_API declaration of the header is in the list
+    import re
+    decl = re.findall(r"RT_API\s+[\w\s\*]+?\b(rt_\w+)\s*\(", open(os.path.join(ROOT, "include", "rt_amd.h")).read())
+    assert sorted(set(decl)) == sorted(rt.AMD_SYMBOLS)
+
+
+def test_create_without_gpu_fails_loudly(rt):
+    """No CPU fallback: without a device rt_create reports RT_ERR_NO_DEVICE and the Python mirror raises."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    ctx = C.c_void_p()
+    assert rt.amd_lib().rt_create(C.byref(ctx), 0, None) == -2
+    try:
+        rt.MetalRenderer(0)
+    except rt.RtError:
+        pass
+    else:
+        raise AssertionError("MetalRenderer() must raise without a GPU")
+
+
+def test_generate_tiles_matches_reference_rules(rt):
+    """ContentView.swift:380-401: row-major 64x64 tiles, edge tiles clipped."""
+    tiles = rt.generate_tiles(1000, 800)
+    assert len(tiles) == 16 * 13
+    assert (tiles[0].x, tiles[0].y, tiles[0].width, tiles[0].height) == (0, 0, 64, 64)
+    assert (tiles[15].x, tiles[15].width) == (960, 40)
+    assert (tiles[-1].y, tiles[-1].height) == (768, 32)
+    tiles = rt.generate_tiles(400, 225)
+    assert len(tiles) == 7 * 4 and tiles[-1].height == 33 and tiles[6].width == 16
+    covered = np.zeros((225, 400), np.int32)
+    for t in tiles:
+        covered[t.y:t.y + t.height, t.x:t.x + t.width] += 1
+    assert (covered == 1).all()
+    assert len(rt.generate_tiles(64, 64)) == 1 and len(rt.generate_tiles(1, 1)) == 1
+
+
+def test_camera_restates_init_ray_tracing(rt):
+    """ContentView.swift:168-213 for the reference's own defaults, checked against the closed form."""
+    u = rt.Uniforms()
+    rt.host_lib().rt_uniforms_reference_defaults(C.byref(u), 1000, 800)
+    assert (u.sampleCount, u.maxRayDepth, u.totalSamples) == (32, 10, 400)
+    assert abs(u.pixelSampleScale - 1 / 32) < 1e-9
+    assert (u.cameraCenter.x, u.cameraCenter.y, u.cameraCenter.z) == (278.0, 278.0, -800.0)
+    h = math.tan(math.radians(40.0) / 2)
+    # w = (0,0,-1), u = cross(up, w) = (-1,0,0), v = cross(w,u) = (0,1,0); viewport height 2h, width 2h*1000/800
+    np.testing.assert_allclose([u.pixelDeltaX.x, u.pixelDeltaX.y, u.pixelDeltaX.z], [-2 * h * 1.25 / 1000, 0, 0], rtol=2e-6, atol=1e-12)
+    np.testing.assert_allclose([u.pixelDeltaY.x, u.pixelDeltaY.y, u.pixelDeltaY.z], [0, -2 * h / 800, 0], rtol=2e-6, atol=1e-12)
+    np.testing.assert_allclose([u.pixelOrigin.x, u.pixelOrigin.y, u.pixelOrigin.z],
+                               [278 + h * 1.25 - h * 1.25 / 1000, 278 + h - h / 800, -799.0], rtol=2e-6)
+    assert u.defocusAngle == 0.0 and u.defocusDiskU.x == 0.0
+    assert (u.globalIllumation.x, u.globalIllumation.w) == (np.float32(0.1), 1.0)
+    assert (u.viewportSize.x, u.viewportSize.y) == (1000.0, 800.0)
+
+
+def test_host_driver_outputs_match_committed_vectors(rt):
+    for name, w, h in [("three_spheres", 400, 225), ("cover", 1920, 1080), ("cornell", 1000, 800), ("nested_glass", 640, 360)]:
+        objs, n = rt.scene(name)
+        u = rt.config_uniforms(name, w, h, 16, 50, n)
+        assert np.array_equal(np.frombuffer(bytes(u), np.uint8), GOLD["uniforms_%s" % name]), name
+    objs, n = rt.scene("cover")
+    assert n == int(GOLD["cover_count"][0])
+    ob = np.frombuffer(bytes(objs), np.uint8)[:160 * n]
+    assert np.array_equal(ob[:160 * 8], GOLD["cover_first8"])
+    fnv = int(np.bitwise_xor.reduce(np.frombuffer(ob.tobytes(), np.uint32) * np.arange(1, len(ob) // 4 + 1, dtype=np.uint32)))
+    assert fnv == int(GOLD["cover_fnv"][0])
+
+
+def test_scenes_have_the_documented_shape(rt):
+    objs, n = rt.scene("cornell")
+    assert n == 7 and [objs[i].type for i in range(7)] == [1, 1, 1, 1, 1, 1, 0]
+    assert objs[5].mat.emission == 15.0 and objs[6].mat.type == rt.DIELECTRIC and objs[6].s.radius == 90.0
+    objs, n = rt.scene("three_spheres")
+    assert n == 5 and {objs[i].mat.type for i in range(5)} == {0, 1, 2}
+    objs, n = rt.scene("cover")
+    assert 470 <= n <= 488 and objs[0].s.radius == 1000.0 and objs[n - 1].mat.type == rt.REFLECTEE
+    for i in range(1, n - 3):
+        c = objs[i].s.center
+        assert objs[i].s.radius == np.float32(0.2) and math.dist((c.x, c.y, c.z), (4, 0.2, 0)) > 0.9
+    objs, n = rt.scene("nested_glass", shells=400)
+    assert n == 401 and objs[1].s.radius == 0.5 and abs(objs[2].mat.refraction_index - 1 / 1.5) < 1e-7
+    objs, n = rt.scene("random_spheres", n=1000)
+    assert n == 1001
+
+
+def test_ray_range_partitions_the_sample_index_space():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("partition", os.path.join(ROOT, "ray-tracing_amd", "partition.py"))
+    part = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(part)
+    for spp in (0, 1, 7, 64, 1000):
+        for world in (1, 2, 3, 4, 8):
+            ranges = [part.ray_range(r, world, spp) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == spp
+            for (b0, e0), (b1, e1) in zip(ranges, ranges[1:]):
+                assert e0 == b1 and b0 <= e0
+            sizes = [e - b for b, e in ranges]
+            assert max(sizes) - min(sizes) <= 1
+    assert part.tile_rows(0, 2, 225) == (0, 128) and part.tile_rows(1, 2, 225) == (128, 225)
