@@ -35,7 +35,6 @@ def parse():
     p.add_argument("--spp", type=int, default=1000)
     p.add_argument("--depth", type=int, default=50)
     p.add_argument("--chunk", type=int, default=-1, help="samples per work item (-1 = library default)")
-    p.add_argument("--arith", type=int, default=0, help="0 strict (bit-identical to the oracle), 1 fused discriminant")
     p.add_argument("--fetch", type=int, default=0, help="0 spheres in LDS, 1 scalar cache")
     p.add_argument("--blocks-per-cu", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -98,7 +97,6 @@ def main():
     r.setupTexture(W, H)
     if args.chunk >= 0:
         r.set_option(rt.RT_OPT_CHUNK, args.chunk)
-    r.set_option(rt.RT_OPT_ARITH, args.arith)
     r.set_option(rt.RT_OPT_SCENE_FETCH, args.fetch)
     r.set_option(rt.RT_OPT_BLOCKS_PER_CU, args.blocks_per_cu)
     objs, n = rt.scene(args.scene)
@@ -168,7 +166,7 @@ def main():
             "data": "synthetic (generated %s scene, fixed seed; random-free camera)" % args.scene,
             "config": {
                 "workload": "%s scene (%d spheres) %dx%d, %d spp, depth %d, one pass" % (args.scene, n, W, H, spp, args.depth),
-                "arithmetic": "strict" if args.arith == 0 else "fused-discriminant",
+                "arithmetic": "hit decisions and radiance bit-identical to the uncontracted IEEE oracle",
                 "samples_per_rank": end - begin,
                 "parallelism": "sample-index split x%d, RCCL reduce of float4 accumulation buffers" % world,
             },

@@ -49,10 +49,8 @@ enum {
 enum {
     RT_OPT_CHUNK = 1,       /* samples per work item of the batch path; 0 = all samples of a call in one
                                item, which reproduces the reference's sequential per-pixel sum order */
-    RT_OPT_ARITH = 2,       /* 0 = strict (no fused multiply-add anywhere; bit-identical intersection
-                               decisions to an uncontracted IEEE evaluation), 1 = fused multiply-add in the
-                               sphere discriminant */
-    RT_OPT_KERNEL = 3,      /* 0 = persistent megakernel, 1 = wavefront (generate/extend/shade queues) */
+    RT_OPT_KERNEL = 3,      /* 0 = persistent megakernel; 2 = the same kernel with in-kernel cycle stamps per phase
+                               (diagnostic, slower; fills rt_stats.phase_cycles) */
     RT_OPT_SCENE_FETCH = 4, /* 0 = spheres staged in LDS per workgroup, 1 = spheres read through the scalar
                                cache from global memory */
     RT_OPT_BLOCKS_PER_CU = 5 /* persistent grid size = this x compute units; 0 = occupancy query */
@@ -130,6 +128,10 @@ struct rt_stats {
     float kernel_ms;
     int grid_blocks;
     int block_threads;
+    /* RT_OPT_KERNEL = 2 only, summed over waves, in shader clock cycles: [0] generate rays / draw work,
+     * [1] sphere filter pass, [2] exact resolve of candidates, [3] quads + hit record, [4] shading,
+     * [5] number of main-loop trips (not cycles). */
+    uint64_t phase_cycles[6];
 };
 RT_API int rt_last_stats(rt_ctx *ctx, struct rt_stats *out);
 

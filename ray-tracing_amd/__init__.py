@@ -80,10 +80,10 @@ class TileInfo(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("segments", C.c_uint64), ("tests", C.c_uint64), ("samples", C.c_uint64), ("kernel_ms", C.c_float),
-                ("grid_blocks", C.c_int), ("block_threads", C.c_int)]
+                ("grid_blocks", C.c_int), ("block_threads", C.c_int), ("phase_cycles", C.c_uint64 * 6)]
 
 
-RT_OPT_CHUNK, RT_OPT_ARITH, RT_OPT_KERNEL, RT_OPT_SCENE_FETCH, RT_OPT_BLOCKS_PER_CU = 1, 2, 3, 4, 5
+RT_OPT_CHUNK, RT_OPT_KERNEL, RT_OPT_SCENE_FETCH, RT_OPT_BLOCKS_PER_CU = 1, 3, 4, 5
 
 # Every symbol include/rt_amd.h declares.
 AMD_SYMBOLS = [

@@ -51,10 +51,10 @@ struct rt_ctx {
     bool stats_pending = false;
 
     int opt_chunk = 64;
-    int opt_arith = 0;
     int opt_kernel = 0;
     int opt_fetch = 0;
     int opt_blocks_per_cu = 0;
+    int opt_waves = 4;
 
     rt_stats last = {};
     std::string err;
@@ -62,9 +62,10 @@ struct rt_ctx {
 
 namespace {
 
-// Largest sphere count staged in LDS (16 B each): 4096 spheres = 64 KiB, which leaves room for two
-// workgroups per compute unit in the 160 KiB LDS.  Larger scenes are read through the scalar cache.
-constexpr int kMaxLdsSpheres = 4096;
+// Largest sphere count staged in LDS (16 B each): 3584 spheres = 56 KiB, which with the 16 KiB of candidate
+// masks leaves room for two workgroups per compute unit in the 160 KiB LDS.  Larger scenes are read
+// through the scalar cache.
+constexpr int kMaxLdsSpheres = 3584;
 
 int fail(rt_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
     if (c) {
@@ -149,7 +150,9 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n) {
         m.inv_ior = 1.0f / o.mat.refraction_index;  // Lib.metal:185
         mats[(size_t)i] = m;
         if (o.type == TYPE_SPHERE) {
-            sph.push_back(make_float4(o.s.center.x, o.s.center.y, o.s.center.z, o.s.radius * o.s.radius));
+            // filter record: r*r inflated by 2^-17 (see closest_sphere in rt_kernels.hip)
+            sph.push_back(make_float4(o.s.center.x, o.s.center.y, o.s.center.z,
+                                      (o.s.radius * o.s.radius) * (1.0f + 0x1p-17f)));
             rad.push_back(o.s.radius);
             sph_obj.push_back(i);
         } else if (o.type == TYPE_QUAD) {
@@ -166,7 +169,7 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n) {
     const float ninf = -std::numeric_limits<float>::infinity();
     while ((int)sph.size() < nsph_pad) {
         sph.push_back(make_float4(0.0f, 0.0f, 0.0f, ninf));
-        rad.push_back(1.0f);
+        rad.push_back(std::numeric_limits<float>::quiet_NaN());
         sph_obj.push_back(-1);
     }
     RT_TRY(upload(ctx, ctx->sph, sph));
@@ -207,7 +210,7 @@ void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
     P.cam.defocusDiskV = ld3(u->defocusDiskV);
     P.cam.defocusAngle = u->defocusAngle;
     P.sky = ld4(u->globalIllumation);
-    P.sph = ctx->sph.ptr;
+    P.sphq = ctx->sph.ptr;
     P.rad = ctx->rad.ptr;
     P.sph_obj = ctx->sph_obj.ptr;
     P.quads = ctx->quads.ptr;
@@ -227,10 +230,8 @@ void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
 
 // Enqueue one trace launch (counter reset, events, kernel).
 int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
-    const bool fast = ctx->opt_arith != 0;
     const bool lds_scene = ctx->opt_fetch == 0 && P.nsph_pad <= kMaxLdsSpheres;
-    const size_t lds_bytes = lds_scene ? (size_t)P.nsph_pad * sizeof(float4) : 0;
-    int per_cu = ctx->opt_blocks_per_cu > 0 ? ctx->opt_blocks_per_cu : trace_blocks_per_cu(fast, lds_scene, lds_bytes);
+    int per_cu = ctx->opt_blocks_per_cu > 0 ? ctx->opt_blocks_per_cu : trace_blocks_per_cu(P, lds_scene, ctx->opt_waves);
     long long blocks = (long long)per_cu * ctx->num_cus;
     long long need = ((long long)P.nitems + 255) / 256;
     if (blocks > need) blocks = need;
@@ -238,7 +239,7 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
     RT_HIP(hipMemsetAsync(ctx->counters, 0, 256, ctx->stream));
     const int slot = (int)(ctx->launches % rt_ctx::kRing);
     RT_HIP(hipEventRecord(ctx->ev0[slot], ctx->stream));
-    RT_HIP(launch_trace(P, fast, lds_scene, (int)blocks, ctx->stream));
+    RT_HIP(launch_trace(P, lds_scene, ctx->opt_kernel == 2, ctx->opt_waves, (int)blocks, ctx->stream));
     RT_HIP(hipEventRecord(ctx->ev1[slot], ctx->stream));
     ctx->launches++;
     ctx->stats_pending = true;
@@ -319,12 +320,8 @@ RT_API int rt_set_option(rt_ctx *ctx, int key, int value) {
             if (value < 0) return fail(ctx, RT_ERR_INVALID, "rt: chunk must be >= 0");
             ctx->opt_chunk = value;
             return RT_OK;
-        case RT_OPT_ARITH:
-            if (value != 0 && value != 1) return fail(ctx, RT_ERR_INVALID, "rt: arith must be 0 or 1");
-            ctx->opt_arith = value;
-            return RT_OK;
         case RT_OPT_KERNEL:
-            if (value != 0) return fail(ctx, RT_ERR_INVALID, "rt: kernel variant not available");
+            if (value != 0 && value != 2) return fail(ctx, RT_ERR_INVALID, "rt: kernel variant not available");
             ctx->opt_kernel = value;
             return RT_OK;
         case RT_OPT_SCENE_FETCH:
@@ -335,6 +332,9 @@ RT_API int rt_set_option(rt_ctx *ctx, int key, int value) {
             if (value < 0 || value > 64) return fail(ctx, RT_ERR_INVALID, "rt: blocks per CU out of range");
             ctx->opt_blocks_per_cu = value;
             return RT_OK;
+        case 6:  // experimental: register budget variant (waves per SIMD the kernel is compiled for)
+            ctx->opt_waves = value;
+            return RT_OK;
     }
     return fail(ctx, RT_ERR_INVALID, "rt: unknown option");
 }
@@ -343,7 +343,6 @@ RT_API int rt_get_option(const rt_ctx *ctx, int key, int *value) {
     if (!ctx || !value) return RT_ERR_INVALID;
     switch (key) {
         case RT_OPT_CHUNK: *value = ctx->opt_chunk; return RT_OK;
-        case RT_OPT_ARITH: *value = ctx->opt_arith; return RT_OK;
         case RT_OPT_KERNEL: *value = ctx->opt_kernel; return RT_OK;
         case RT_OPT_SCENE_FETCH: *value = ctx->opt_fetch; return RT_OK;
         case RT_OPT_BLOCKS_PER_CU: *value = ctx->opt_blocks_per_cu; return RT_OK;
@@ -540,7 +539,7 @@ RT_API int rt_first_hit(rt_ctx *ctx, const Uniforms *u, const Object *objs, int 
     int *dids = nullptr;
     RT_HIP(hipMalloc((void **)&d4, n * sizeof(float4)));
     hipError_t e = hipMalloc((void **)&dids, n * sizeof(int));
-    if (e == hipSuccess) e = launch_first_hit(P, ctx->opt_arith != 0, d4, dids, ctx->stream);
+    if (e == hipSuccess) e = launch_first_hit(P, d4, dids, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out4, d4, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(ids, dids, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -558,13 +557,14 @@ RT_API int rt_last_stats(rt_ctx *ctx, rt_stats *out) {
         float ms = 0.0f;
         const int slot = (int)((ctx->launches - 1) % rt_ctx::kRing);
         RT_HIP(hipEventElapsedTime(&ms, ctx->ev0[slot], ctx->ev1[slot]));
-        uint32_t host[4] = {0, 0, 0, 0};
+        uint32_t host[16] = {0};
         RT_HIP(hipMemcpyAsync(host, ctx->counters, sizeof host, hipMemcpyDeviceToHost, ctx->stream));
         RT_HIP(hipStreamSynchronize(ctx->stream));
         uint64_t seg = (uint64_t)host[2] | ((uint64_t)host[3] << 32);
         ctx->last.kernel_ms = ms;
         ctx->last.segments = seg;
         ctx->last.tests = seg * (uint64_t)ctx->nobj;
+        for (int i = 0; i < 6; ++i) ctx->last.phase_cycles[i] = (uint64_t)host[4 + 2 * i] | ((uint64_t)host[5 + 2 * i] << 32);
         ctx->stats_pending = false;
     }
     *out = ctx->last;

@@ -3,7 +3,8 @@
 // Arithmetic contract: every float operation below is a single IEEE binary32
 // operation in the written order.  This file is compiled with -ffp-contract=off;
 // division and square root are hipcc's correctly rounded forms.  The only fused
-// multiply-adds are the explicit __builtin_fmaf calls of the FAST discriminant.
+// multiply-adds in the library are the explicit __builtin_fmaf calls of the
+// conservative sphere filter in rt_kernels.hip, whose result never decides a hit.
 // Metal built-ins are taken at their Metal Shading Language specification
 // formulas (dot = x*x'+y*y'+z*z' left to right, normalize = v / sqrt(dot(v,v)),
 // reflect = I - 2*dot(N,I)*N, refract with k = 1 - eta*eta*(1 - dot(N,I)^2),
@@ -140,23 +141,6 @@ struct Hit {
 RT_DEV void apply_normals(Hit &h, V3 dir, V3 outward) {
     h.front = dot(dir, outward) < 0.0f;
     h.normal = h.front ? outward : -outward;
-}
-
-// Sphere discriminant of Lib.metal:216-221 from the compact record s = (cx, cy, cz, r*r).
-template <bool FAST>
-RT_DEV float sphere_disc(f4v s, V3 o, V3 d, float a, float &b_out) {
-    float ocx = o.x - s.x, ocy = o.y - s.y, ocz = o.z - s.z;
-    if constexpr (FAST) {
-        float b = __builtin_fmaf(ocz, d.z, __builtin_fmaf(ocy, d.y, ocx * d.x));
-        float c = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx)) - s.w;
-        b_out = b;
-        return __builtin_fmaf(b, b, -(a * c));
-    } else {
-        float b = ocx * d.x + ocy * d.y + ocz * d.z;
-        float c = (ocx * ocx + ocy * ocy + ocz * ocz) - s.w;
-        b_out = b;
-        return b * b - a * c;
-    }
 }
 
 // Root selection of Lib.metal:230-238 against the interval (kTMin, tmax).  Returns true and the root.

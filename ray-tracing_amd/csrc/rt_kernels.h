@@ -14,8 +14,8 @@ enum { kModeAccum = 0, kModeProgressive = 1 };
 struct TraceParams {
     Camera cam;
     V4 sky;                 // Uniforms.globalIllumation
-    const float4 *sph;      // [nsph_pad] (cx, cy, cz, r*r); padding records have r*r = -inf and never hit
-    const float *rad;       // [nsph_pad] radius
+    const float4 *sphq;     // [nsph_pad] filter records (cx, cy, cz, r*r * (1 + 2^-17)); padding: r2q = -inf
+    const float *rad;       // [nsph_pad] radius as given (padding: NaN, which can never hit)
     const int *sph_obj;     // [nsph_pad] object index of each sphere slot
     const QuadDev *quads;   // [nquad]
     const MatDev *mats;     // [nobj] indexed by object index
@@ -28,15 +28,16 @@ struct TraceParams {
     int chunk;              // samples per work item
     uint32_t nitems;        // tileW * tileH * ceil((ray_end - ray_begin) / chunk)
     uint32_t *counter;      // work-item counter, zeroed before the launch
-    unsigned long long *seg_counter;  // += number of closest-hit searches
+    unsigned long long *seg_counter;  // [0] += number of closest-hit searches; [1..6] += phase cycle stamps of the
+                                      // diagnostic instantiation
     float4 *planes;         // kModeAccum: [nchunks][width*height] partial sums, one plane per chunk
     float4 *target;         // kModeProgressive: rgba32Float render target
     int mode;
     int spp_pass;           // kModeProgressive: Uniforms.sampleCount
 };
 
-hipError_t launch_trace(const TraceParams &P, bool fast, bool lds_scene, int blocks, hipStream_t stream);
-int trace_blocks_per_cu(bool fast, bool lds_scene, size_t lds_bytes);
+hipError_t launch_trace(const TraceParams &P, bool lds_scene, bool profile, int waves, int blocks, hipStream_t stream);
+int trace_blocks_per_cu(const TraceParams &P, bool lds_scene, int waves);
 hipError_t launch_fold(float4 *accum, const float4 *planes, int nplanes, int width, int height, int tileX, int tileY,
                        int tileW, int tileH, hipStream_t stream);
 hipError_t launch_resolve(float4 *target, const float4 *accum, int npix, int spp, hipStream_t stream);
@@ -46,6 +47,6 @@ hipError_t launch_error_pixels(float4 *target, int width, int height, int gw, in
                                int tileH, int all_fail, hipStream_t stream);
 hipError_t launch_present_bgra8(const float4 *target, int width, int height, uint32_t *out, int out_w, int out_h,
                                 hipStream_t stream);
-hipError_t launch_first_hit(const TraceParams &P, bool fast, float4 *out4, int *ids, hipStream_t stream);
+hipError_t launch_first_hit(const TraceParams &P, float4 *out4, int *ids, hipStream_t stream);
 
 }  // namespace rt

@@ -1,7 +1,7 @@
 /*
  * rt_cli.c -- command-line driver: renders one of the named scenes on one GPU and writes a PPM.
  *   rt_render [--scene cover|three_spheres|cornell|nested_glass|random_spheres] [--width W] [--height H]
- *             [--spp N] [--depth D] [--progressive PASSES] [--chunk C] [--fast] [--out file.ppm]
+ *             [--spp N] [--depth D] [--progressive PASSES] [--chunk C] [--fetch 0|1] [--stamps] [--out file.ppm]
  * --progressive runs the reference's tile-by-tile loop (PASSES passes of --spp samples each);
  * otherwise the whole image is traced in one batch call.
  */
@@ -20,7 +20,7 @@ static double now_s(void) {
 
 int main(int argc, char **argv) {
     const char *scene = "cover", *out = NULL;
-    int width = 1200, height = 675, spp = 100, depth = 50, passes = 0, chunk = -1, fast = 0;
+    int width = 1200, height = 675, spp = 100, depth = 50, passes = 0, chunk = -1, fetch = 0, stamps = 0, waves = 4;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--scene") && i + 1 < argc) scene = argv[++i];
         else if (!strcmp(argv[i], "--width") && i + 1 < argc) width = atoi(argv[++i]);
@@ -29,7 +29,9 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--depth") && i + 1 < argc) depth = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--progressive") && i + 1 < argc) passes = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--chunk") && i + 1 < argc) chunk = atoi(argv[++i]);
-        else if (!strcmp(argv[i], "--fast")) fast = 1;
+        else if (!strcmp(argv[i], "--fetch") && i + 1 < argc) fetch = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--stamps")) stamps = 1;
+        else if (!strcmp(argv[i], "--waves") && i + 1 < argc) waves = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
@@ -55,7 +57,9 @@ int main(int argc, char **argv) {
     int rc = rt_create(&ctx, 0, NULL);
     if (rc != RT_OK) { fprintf(stderr, "rt_create failed: %d\n", rc); return 1; }
     if (chunk >= 0) rt_set_option(ctx, RT_OPT_CHUNK, chunk);
-    rt_set_option(ctx, RT_OPT_ARITH, fast);
+    rt_set_option(ctx, RT_OPT_SCENE_FETCH, fetch);
+    if (stamps) rt_set_option(ctx, RT_OPT_KERNEL, 2);
+    rt_set_option(ctx, 6, waves);
 
     double t0, t1;
     if (passes > 0) {
@@ -88,6 +92,14 @@ int main(int argc, char **argv) {
                "%.2f TFLOP/s algorithmic (23 flop x %d objects x segments)\n",
                scene, width, height, spp, depth, t1 - t0, st.kernel_ms, msamples / (t1 - t0),
                (double)st.segments / ((double)width * height * spp), 23.0 * (double)st.tests / (st.kernel_ms * 1e-3) * 1e-12, n);
+        if (stamps) {
+            double tot = 0;
+            for (int i = 0; i < 5; ++i) tot += (double)st.phase_cycles[i];
+            const char *names[5] = {"generate", "filter", "resolve", "quads+record", "shade"};
+            for (int i = 0; i < 5; ++i)
+                printf("  %-13s %6.2f %% of wave cycles, %.0f cycles per loop trip\n", names[i], 100.0 * (double)st.phase_cycles[i] / tot,
+                       (double)st.phase_cycles[i] / (double)st.phase_cycles[5]);
+        }
     }
     if (out) {
         float *img = (float *)malloc((size_t)width * height * 4 * sizeof(float));

@@ -1,8 +1,7 @@
 """GPU: the HIP path, called through the C-ABI, against the CPU oracle and the committed vectors.
 
-Bar (strict arithmetic, the default): bit-identical float images, exact first-hit object ids.
-Bar for RT_OPT_ARITH=1 (fused multiply-add in the discriminant): exact-or-better than the tolerance the
-task states for converged images, PSNR >= 45 dB against the oracle.
+Bar: bit-identical float images and first-hit buffers (the task's stated tolerance -- exact object ids, 1e-5
+relative on t and normal, PSNR >= 45 dB on converged images -- is met with equality).
 """
 import ctypes as C
 import os
@@ -19,7 +18,6 @@ GOLD = np.load(os.path.join(HERE, "golden", "oracle_vectors.npz"))
 
 
 def strict(r, rt, chunk=0, fetch=0):
-    r.set_option(rt.RT_OPT_ARITH, 0)
     r.set_option(rt.RT_OPT_SCENE_FETCH, fetch)
     r.set_option(rt.RT_OPT_CHUNK, chunk)
     r.set_option(rt.RT_OPT_BLOCKS_PER_CU, 0)
@@ -272,22 +270,3 @@ def test_error_codes(rt):
     assert lib.rt_set_option(r._ctx, 99, 0) == -1
     assert b"rt" in lib.rt_last_error(r._ctx)
     r.close()
-
-
-def test_fused_discriminant_mode_meets_psnr_bar(rt, oracle, renderer):
-    """RT_OPT_ARITH=1 is not bit-exact (different roundings flip a few hit decisions); it must still clear the
-    45 dB bar for converged images and keep first-hit ids equal on all but grazing pixels."""
-    w, h, spp = 240, 135, 32
-    objs, n = rt.scene("cover")
-    u = rt.config_uniforms("cover", w, h, spp, 50, n)
-    renderer.setupTexture(w, h)
-    renderer.set_option(rt.RT_OPT_ARITH, 1)
-    try:
-        img = renderer.renderImage(u, objs, n, chunk=0)
-        _, ids = renderer.firstHit(u, objs, n)
-    finally:
-        renderer.set_option(rt.RT_OPT_ARITH, 0)
-    want = oracle.image(u, objs, w, h)
-    assert psnr(img, want) >= 45.0
-    _, want_ids = oracle.first_hit(u, objs, w, h)
-    assert (ids != want_ids).mean() < 1e-3

@@ -44,33 +44,29 @@ def main():
         r.setupTexture(w, h)
         for fetch in (0, 1):
             r.set_option(rt.RT_OPT_SCENE_FETCH, fetch)
-            for arith in (0, 1):
-                r.set_option(rt.RT_OPT_ARITH, arith)
-                for chunk in (0, 8):
-                    img = r.renderImage(u, objs, n, chunk=chunk)
-                    st = r.lastStats()
-                    compare("%s fetch=%d arith=%d chunk=%d (%.1f ms, seg/s %.2f)" % (name, fetch, arith, chunk, st.kernel_ms, st.segments / (w * h * spp)), img, ref)
+            for chunk in (0, 8):
+                img = r.renderImage(u, objs, n, chunk=chunk)
+                st = r.lastStats()
+                compare("%s fetch=%d chunk=%d (%.1f ms, seg/s %.2f)" % (name, fetch, chunk, st.kernel_ms, st.segments / (w * h * spp)), img, ref)
     # timings
-    name, w, h, spp, depth = "cover", 1200, 675, 16, 50
+    name, w, h, spp, depth = "cover", 1200, 675, 128, 50
     objs, n = rt.scene(name)
     u = rt.config_uniforms(name, w, h, spp, depth, n)
     r.setupTexture(w, h)
     r.setScene(objs, n)
     for fetch in (0, 1):
         r.set_option(rt.RT_OPT_SCENE_FETCH, fetch)
-        for arith in (0, 1):
-            r.set_option(rt.RT_OPT_ARITH, arith)
-            for bpc in (0, 2, 4, 8):
-                r.set_option(rt.RT_OPT_BLOCKS_PER_CU, bpc)
-                for chunk in (16, 4):
-                    r.set_option(rt.RT_OPT_CHUNK, chunk)
-                    r.accumClear()
-                    r.render(u, None, 0, 0, spp)
-                    r.synchronize()
-                    st = r.lastStats()
-                    tf = 23.0 * st.tests / (st.kernel_ms * 1e-3) * 1e-12
-                    print("cover %dx%d %dspp fetch=%d arith=%d blocks/CU=%d(grid %d) chunk=%d: %.1f ms  %.1f Msamples/s  %.2f seg/sample  %.1f TFLOP/s alg (%.1f%% of 157.3)"
-                          % (w, h, spp, fetch, arith, bpc, st.grid_blocks, chunk, st.kernel_ms, w * h * spp / st.kernel_ms * 1e-3, st.segments / (w * h * spp), tf, tf / 1.573), flush=True)
+        for bpc in (0, 2, 4, 8):
+            r.set_option(rt.RT_OPT_BLOCKS_PER_CU, bpc)
+            for chunk in (32, 8):
+                r.set_option(rt.RT_OPT_CHUNK, chunk)
+                r.accumClear()
+                r.render(u, None, 0, 0, spp)
+                r.synchronize()
+                st = r.lastStats()
+                tf = 23.0 * st.tests / (st.kernel_ms * 1e-3) * 1e-12
+                print("cover %dx%d %dspp fetch=%d blocks/CU=%d(grid %d) chunk=%d: %.1f ms  %.1f Msamples/s  %.2f seg/sample  %.1f TFLOP/s alg (%.1f%% of 157.3)"
+                      % (w, h, spp, fetch, bpc, st.grid_blocks, chunk, st.kernel_ms, w * h * spp / st.kernel_ms * 1e-3, st.segments / (w * h * spp), tf, tf / 1.573), flush=True)
     r.close()
 
 
