@@ -51,9 +51,12 @@ enum {
                                item, which reproduces the reference's sequential per-pixel sum order */
     RT_OPT_KERNEL = 3,      /* 0 = persistent megakernel; 2 = the same kernel with in-kernel cycle stamps per phase
                                (diagnostic, slower; fills rt_stats.phase_cycles) */
-    RT_OPT_SCENE_FETCH = 4, /* 0 = spheres staged in LDS per workgroup, 1 = spheres read through the scalar
-                               cache from global memory */
-    RT_OPT_BLOCKS_PER_CU = 5 /* persistent grid size = this x compute units; 0 = occupancy query */
+    RT_OPT_SCENE_FETCH = 4, /* where the sphere filter reads its records: 0 = staged in LDS once per workgroup and
+                               broadcast-read (default; scenes up to 1792 spheres, larger ones fall back to 1),
+                               1 = through the scalar cache into scalar registers */
+    RT_OPT_BLOCKS_PER_CU = 5, /* persistent grid size = this x compute units; 0 = occupancy query */
+    RT_OPT_FILTER = 6       /* 0 = compact 9-instruction sphere filter where the scene allows it (default),
+                               1 = always the translation-invariant 11-instruction filter; results are identical */
 };
 
 /* setupMetal (ContentView.swift:328-356): device, queue, pipelines.  `device` is the HIP device ordinal.

@@ -5,6 +5,7 @@
 // (reference: "Ray Tracer/ContentView.swift":328-378, 661-709).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -35,12 +36,13 @@ struct rt_ctx {
     DevBuf<float4> target, accum, planes;
 
     // compact scene
-    DevBuf<float4> sph;
+    DevBuf<float4> sph, sphc;
     DevBuf<float> rad;
     DevBuf<int> sph_obj;
     DevBuf<QuadDev> quads;
     DevBuf<MatDev> mats;
-    int nsph = 0, nsph_pad = 0, nquad = 0, nobj = 0;
+    int nsph = 0, ngroups = 0, nquad = 0, nobj = 0;
+    float oo_limit = -1.0f;
     bool scene_resident = false;
 
     uint32_t *counters = nullptr;  // 256 B: [0] work counter (u32), [2..3] segment counter (u64)
@@ -54,7 +56,7 @@ struct rt_ctx {
     int opt_kernel = 0;
     int opt_fetch = 0;
     int opt_blocks_per_cu = 0;
-    int opt_waves = 4;
+    int opt_filter = 0;
 
     rt_stats last = {};
     std::string err;
@@ -62,10 +64,9 @@ struct rt_ctx {
 
 namespace {
 
-// Largest sphere count staged in LDS (16 B each): 3584 spheres = 56 KiB, which with the 16 KiB of candidate
-// masks leaves room for two workgroups per compute unit in the 160 KiB LDS.  Larger scenes are read
-// through the scalar cache.
-constexpr int kMaxLdsSpheres = 3584;
+// Largest sphere count the optional LDS staging accepts (two 16-byte records each): 1792 spheres = 56 KiB,
+// which with the 16 KiB of candidate words leaves room for two workgroups per compute unit in the 160 KiB LDS.
+constexpr int kMaxLdsSpheres = 1792;
 
 int fail(rt_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
     if (c) {
@@ -163,16 +164,40 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n) {
             quads.push_back(q);
         }  // any other type never hits (Lib.metal:283-291)
     }
-    int nsph = (int)sph.size();
-    int nsph_pad = (nsph + 31) / 32 * 32;
-    if (nsph_pad == 0) nsph_pad = 32;
+    const int nsph = (int)sph.size();
+    const int ngroups = (nsph + 3) / 4;
+    const int nslots = 4 * (ngroups + 1);  // one spare group: the filter prefetches one group past the end
+    // Compact filter records and the origin limit below which a ray may use them (rt_trace.hip, closest_sphere).
+    std::vector<float4> sphc;
+    std::vector<double> budget;
+    const double slack = 0x1p-16;
+    for (int i = 0; i < nsph; ++i) {
+        const Object &o = objs[sph_obj[(size_t)i]];
+        const double cx = o.s.center.x, cy = o.s.center.y, cz = o.s.center.z;
+        const double r2 = (double)(o.s.radius * o.s.radius);
+        const double cc = cx * cx + cy * cy + cz * cz;
+        const double kq = cc * (1.0 - slack) - r2 * (1.0 + slack);
+        float f = (float)kq;
+        if ((double)f > kq) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());  // round toward -inf
+        sphc.push_back(make_float4(o.s.center.x, o.s.center.y, o.s.center.z, f));
+        budget.push_back(0.25 * r2 / slack - cc);  // |o|^2 at which this sphere's filter radius^2 has grown by 25 %
+    }
+    float oo_limit = -1.0f;  // no sphere: the general filter (nothing to test either way)
+    if (nsph > 0) {
+        size_t k = (size_t)(nsph / 10);
+        std::nth_element(budget.begin(), budget.begin() + (long)k, budget.end());
+        double lim = budget[k];  // 10th percentile: 90 % of the spheres keep their inflation below 25 %
+        oo_limit = lim > 0.0 ? (float)std::min(lim, 1e30) : -1.0f;
+    }
     const float ninf = -std::numeric_limits<float>::infinity();
-    while ((int)sph.size() < nsph_pad) {
-        sph.push_back(make_float4(0.0f, 0.0f, 0.0f, ninf));
+    while ((int)sph.size() < nslots) {
+        sph.push_back(make_float4(0.0f, 0.0f, 0.0f, ninf));                                       // q = -inf
+        sphc.push_back(make_float4(0.0f, 0.0f, 0.0f, std::numeric_limits<float>::infinity()));    // q = -inf
         rad.push_back(std::numeric_limits<float>::quiet_NaN());
         sph_obj.push_back(-1);
     }
     RT_TRY(upload(ctx, ctx->sph, sph));
+    RT_TRY(upload(ctx, ctx->sphc, sphc));
     RT_TRY(upload(ctx, ctx->rad, rad));
     RT_TRY(upload(ctx, ctx->sph_obj, sph_obj));
     RT_TRY(upload(ctx, ctx->quads, quads));
@@ -180,7 +205,8 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n) {
     // the host vectors die at return: wait for the copies
     RT_HIP(hipStreamSynchronize(ctx->stream));
     ctx->nsph = nsph;
-    ctx->nsph_pad = nsph_pad;
+    ctx->ngroups = ngroups;
+    ctx->oo_limit = oo_limit;
     ctx->nquad = (int)quads.size();
     ctx->nobj = n;
     return RT_OK;
@@ -210,19 +236,20 @@ void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
     P.cam.defocusDiskV = ld3(u->defocusDiskV);
     P.cam.defocusAngle = u->defocusAngle;
     P.sky = ld4(u->globalIllumation);
-    P.sphq = ctx->sph.ptr;
+    P.sphg = ctx->sph.ptr;
+    P.sphc = ctx->sphc.ptr;
     P.rad = ctx->rad.ptr;
     P.sph_obj = ctx->sph_obj.ptr;
     P.quads = ctx->quads.ptr;
     P.mats = ctx->mats.ptr;
-    P.nsph = ctx->nsph;
-    P.nsph_pad = ctx->nsph_pad;
+    P.ngroups = ctx->ngroups;
     P.nquad = ctx->nquad;
-    P.nobj = ctx->nobj;
+    P.oo_limit = ctx->opt_filter == 1 ? -1.0f : ctx->oo_limit;
     P.width = ctx->width;
     P.height = ctx->height;
     P.pass = u->currentSample;
     P.maxDepth = u->maxRayDepth;
+    P.tileX = 0; P.tileY = 0; P.tileW = ctx->width; P.tileH = ctx->height;
     P.counter = ctx->counters;
     P.seg_counter = (unsigned long long *)(ctx->counters + 2);
     P.target = ctx->target.ptr;
@@ -230,8 +257,8 @@ void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
 
 // Enqueue one trace launch (counter reset, events, kernel).
 int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
-    const bool lds_scene = ctx->opt_fetch == 0 && P.nsph_pad <= kMaxLdsSpheres;
-    int per_cu = ctx->opt_blocks_per_cu > 0 ? ctx->opt_blocks_per_cu : trace_blocks_per_cu(P, lds_scene, ctx->opt_waves);
+    const bool lds_scene = ctx->opt_fetch == 0 && 4 * P.ngroups <= kMaxLdsSpheres;
+    int per_cu = ctx->opt_blocks_per_cu > 0 ? ctx->opt_blocks_per_cu : trace_blocks_per_cu(P, lds_scene);
     long long blocks = (long long)per_cu * ctx->num_cus;
     long long need = ((long long)P.nitems + 255) / 256;
     if (blocks > need) blocks = need;
@@ -239,7 +266,7 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
     RT_HIP(hipMemsetAsync(ctx->counters, 0, 256, ctx->stream));
     const int slot = (int)(ctx->launches % rt_ctx::kRing);
     RT_HIP(hipEventRecord(ctx->ev0[slot], ctx->stream));
-    RT_HIP(launch_trace(P, lds_scene, ctx->opt_kernel == 2, ctx->opt_waves, (int)blocks, ctx->stream));
+    RT_HIP(launch_trace(P, lds_scene, ctx->opt_kernel == 2, (int)blocks, ctx->stream));
     RT_HIP(hipEventRecord(ctx->ev1[slot], ctx->stream));
     ctx->launches++;
     ctx->stats_pending = true;
@@ -298,6 +325,7 @@ RT_API void rt_destroy(rt_ctx *ctx) {
     (void)hipFree(ctx->accum.ptr);
     (void)hipFree(ctx->planes.ptr);
     (void)hipFree(ctx->sph.ptr);
+    (void)hipFree(ctx->sphc.ptr);
     (void)hipFree(ctx->rad.ptr);
     (void)hipFree(ctx->sph_obj.ptr);
     (void)hipFree(ctx->quads.ptr);
@@ -332,8 +360,9 @@ RT_API int rt_set_option(rt_ctx *ctx, int key, int value) {
             if (value < 0 || value > 64) return fail(ctx, RT_ERR_INVALID, "rt: blocks per CU out of range");
             ctx->opt_blocks_per_cu = value;
             return RT_OK;
-        case 6:  // experimental: register budget variant (waves per SIMD the kernel is compiled for)
-            ctx->opt_waves = value;
+        case RT_OPT_FILTER:
+            if (value != 0 && value != 1) return fail(ctx, RT_ERR_INVALID, "rt: filter must be 0 or 1");
+            ctx->opt_filter = value;
             return RT_OK;
     }
     return fail(ctx, RT_ERR_INVALID, "rt: unknown option");
@@ -346,6 +375,7 @@ RT_API int rt_get_option(const rt_ctx *ctx, int key, int *value) {
         case RT_OPT_KERNEL: *value = ctx->opt_kernel; return RT_OK;
         case RT_OPT_SCENE_FETCH: *value = ctx->opt_fetch; return RT_OK;
         case RT_OPT_BLOCKS_PER_CU: *value = ctx->opt_blocks_per_cu; return RT_OK;
+        case RT_OPT_FILTER: *value = ctx->opt_filter; return RT_OK;
     }
     return RT_ERR_INVALID;
 }

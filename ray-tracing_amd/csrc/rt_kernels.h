@@ -1,4 +1,4 @@
-// rt_kernels.h -- kernel parameter block and launcher declarations shared by rt_kernels.hip and rt_api.hip.
+// rt_kernels.h -- kernel parameter block and launcher declarations shared by the .hip files.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -10,20 +10,28 @@ namespace rt {
 
 enum { kModeAccum = 0, kModeProgressive = 1 };
 
-// Everything one trace launch needs.  Passed by value in the kernel argument segment.
+// Everything one trace launch needs.  Passed by value in the kernel argument segment.  The first block is
+// read on every trip of the kernel's main loop and lives in scalar registers; the kernel reads the second
+// block (camera, work-item bookkeeping, output buffers) from the argument segment only where it is used, so
+// it does not occupy registers during the sphere loop.
 struct TraceParams {
-    Camera cam;
-    V4 sky;                 // Uniforms.globalIllumation
-    const float4 *sphq;     // [nsph_pad] filter records (cx, cy, cz, r*r * (1 + 2^-17)); padding: r2q = -inf
-    const float *rad;       // [nsph_pad] radius as given (padding: NaN, which can never hit)
-    const int *sph_obj;     // [nsph_pad] object index of each sphere slot
+    // ---- hot ----
+    const float4 *sphg;     // [4*(ngroups+1)] general filter records (cx, cy, cz, r*r * (1 + 2^-17))
+    const float4 *sphc;     // [4*(ngroups+1)] compact filter records (cx, cy, cz, |c|^2 * (1 - 2^-17) - r*r * (1 + 2^-17))
+    const float *rad;       // [4*(ngroups+1)] radius as given (padding: NaN, which can never hit)
+    const int *sph_obj;     // [4*(ngroups+1)] object index of each sphere slot
     const QuadDev *quads;   // [nquad]
     const MatDev *mats;     // [nobj] indexed by object index
-    int nsph, nsph_pad, nquad, nobj;
+    int ngroups;            // sphere slots / 4 (slots are padded to a multiple of 4 with never-hit records)
+    int nquad;
+    float oo_limit;         // rays with |origin|^2 above this use the general filter (see rt_trace.hip)
+    int maxDepth;           // Uniforms.maxRayDepth
+    V4 sky;                 // Uniforms.globalIllumation
+    // ---- cold ----
+    Camera cam;
     int width, height;      // render target size
     int tileX, tileY, tileW, tileH;
     int pass;               // Uniforms.currentSample
-    int maxDepth;           // Uniforms.maxRayDepth
     int ray_begin, ray_end; // rayIndex range traced by this launch
     int chunk;              // samples per work item
     uint32_t nitems;        // tileW * tileH * ceil((ray_end - ray_begin) / chunk)
@@ -36,8 +44,9 @@ struct TraceParams {
     int spp_pass;           // kModeProgressive: Uniforms.sampleCount
 };
 
-hipError_t launch_trace(const TraceParams &P, bool lds_scene, bool profile, int waves, int blocks, hipStream_t stream);
-int trace_blocks_per_cu(const TraceParams &P, bool lds_scene, int waves);
+hipError_t launch_trace(const TraceParams &P, bool lds_scene, bool profile, int blocks, hipStream_t stream);
+int trace_blocks_per_cu(const TraceParams &P, bool lds_scene);
+hipError_t launch_first_hit(const TraceParams &P, float4 *out4, int *ids, hipStream_t stream);
 hipError_t launch_fold(float4 *accum, const float4 *planes, int nplanes, int width, int height, int tileX, int tileY,
                        int tileW, int tileH, hipStream_t stream);
 hipError_t launch_resolve(float4 *target, const float4 *accum, int npix, int spp, hipStream_t stream);
@@ -47,6 +56,5 @@ hipError_t launch_error_pixels(float4 *target, int width, int height, int gw, in
                                int tileH, int all_fail, hipStream_t stream);
 hipError_t launch_present_bgra8(const float4 *target, int width, int height, uint32_t *out, int out_w, int out_h,
                                 hipStream_t stream);
-hipError_t launch_first_hit(const TraceParams &P, float4 *out4, int *ids, hipStream_t stream);
 
 }  // namespace rt

@@ -1,0 +1,490 @@
+// rt_trace.hip -- the path-tracing kernel for gfx950 (wave64) and its launchers.
+//
+// Replaces the reference's Metal compute kernel (reference: "Ray Tracer/Shaders.metal":91-161 with the device
+// library "Ray Tracer/Lib.metal").
+//
+// trace_kernel is a persistent kernel: every lane owns one work item at a time -- (pixel, range of sample
+// indices) -- drawn from a global counter, traces the item's samples one ray segment per trip of the main
+// loop, and draws the next item when done, so lanes never wait for a neighbour's longer path.
+//
+// One trip = one closest-hit search per lane (the reference's brute-force world_hit loop over all objects):
+//   pass A  every sphere against every lane's ray with a conservative sign test (9 or 11 FMA-class vector
+//           instructions per sphere); the sphere records are wave-uniform and are read through the scalar
+//           cache into scalar registers (or, optionally, from LDS); one result bit per sphere is kept;
+//   pass B  the few spheres whose bit is set are resolved per lane with the reference's exact arithmetic
+//           (uncontracted discriminant, sqrt, divisions, strict interval test) in index order;
+//   quads, hit record, material scatter, and regeneration of finished paths follow.
+// Pass A may only over-report; every hit decision is made in pass B, so results are bit-identical to an
+// uncontracted IEEE evaluation of the reference's code.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_device.hpp"
+#include "rt_kernels.h"
+
+namespace rt {
+
+constexpr int kWordGroups = 8;    // groups of 4 spheres per 32-bit candidate word
+constexpr int kRoundWords = 16;   // candidate words per resolve round (512 spheres)
+constexpr int kMaskWordsPerWave = kRoundWords * 64;  // LDS words per wave: one word per lane per round word
+
+// Filter margins (see closest_sphere).  kDirScale inflates the b side of both filters; the c side is inflated
+// on the host when the records are built: r*r * (1 + 2^-17) in the general records, and a slack of
+// kCompactSlack * (|o|^2 + |c|^2 + r^2) in the compact form, whose per-ray share is applied here.
+constexpr float kDirScale = 1.0f + 0x1p-18f;
+constexpr float kCompactSlack = 0x1p-16f;
+
+typedef const f4v __attribute__((address_space(4))) *const_f4_ptr;
+
+struct Rec4 { f4v r0, r1, r2, r3; };
+
+// Where pass A reads its records from.  g = generic pointer to the same array for the per-lane reads of pass B.
+template <bool LDS_SCENE>
+struct Fetch;
+template <>
+struct Fetch<false> {  // scalar cache: uniform address -> s_load_dwordx16 into scalar registers
+    const_f4_ptr p;
+    const f4v *g;
+    RT_DEV Rec4 load4(int group) const {
+        const_f4_ptr q = p + 4 * group;
+        Rec4 r = {q[0], q[1], q[2], q[3]};
+        return r;
+    }
+    // Scalar loads return out of order, so the only wait is "all of them".  Forcing that wait here, before the
+    // next group's load is issued, keeps exactly one group in flight behind the one being computed on.
+    // The records pass through the statement as read-write operands so that the arithmetic on them cannot be
+    // scheduled above it.
+    RT_DEV void settle(Rec4 &r) const {
+        asm volatile("" : "+s"(r.r0), "+s"(r.r1), "+s"(r.r2), "+s"(r.r3)::"memory");
+    }
+    RT_DEV f4v load1(int k) const { return g[k]; }
+};
+template <>
+struct Fetch<true> {  // LDS: records staged once per workgroup, read with a wave-uniform address (broadcast)
+    const f4v *p;
+    RT_DEV Rec4 load4(int group) const {
+        const f4v *q = p + 4 * group;
+        Rec4 r = {q[0], q[1], q[2], q[3]};
+        return r;
+    }
+    RT_DEV void settle(Rec4 &) const {}
+    RT_DEV f4v load1(int k) const { return p[k]; }
+};
+
+// Optional in-kernel cycle stamps (diagnostic instantiation only): wave-level s_memtime differences summed
+// per phase.  With PROF = false every member function is empty and nothing is emitted.
+template <bool PROF>
+struct Prof {
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};  // 0 regenerate, 1 filter pass, 2 resolve pass, 3 quads+hit record, 4 shade, 5 trips
+    uint64_t last = 0;
+    RT_DEV void start() { if constexpr (PROF) last = __builtin_amdgcn_s_memtime(); }
+    RT_DEV void lap(int i) {
+        if constexpr (PROF) {
+            uint64_t now = __builtin_amdgcn_s_memtime();
+            t[i] += now - last;
+            last = now;
+        }
+    }
+    RT_DEV void count(int i) { if constexpr (PROF) t[i] += 1; }
+};
+
+// Per-ray constants of the two filters.
+struct RayGeneral { V3 o, dn; };                                          // dn = d * kDirScale / |d|
+struct RayCompact { float ndnx, ndny, ndnz, odn, m2ox, m2oy, m2oz, oo1; };  // -dn, o.dn, -2*o, |o|^2 * (1 - kCompactSlack)
+
+// General filter, record (c, r2q): q = (oc.dn)^2 - (|oc|^2 - r2q), oc = o - c.  11 instructions with the mask.
+RT_DEV uint32_t sphere_bit(uint32_t m, f4v r, const RayGeneral &y) {
+    float ocx = y.o.x - r.x, ocy = y.o.y - r.y, ocz = y.o.z - r.z;
+    float bn = __builtin_fmaf(ocz, y.dn.z, __builtin_fmaf(ocy, y.dn.y, ocx * y.dn.x));
+    float cq = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, -r.w)));
+    float q = __builtin_fmaf(bn, bn, -cq);
+    return __builtin_amdgcn_alignbit(m, __float_as_uint(q), 31);  // (m << 1) | sign(q)
+}
+// Compact filter, record (c, kq): the same quantity expanded so that no per-sphere subtraction is needed,
+// bn = o.dn - c.dn and |oc|^2 - r2q - slack = |o|^2(1-k) - 2 o.c + kq.  9 instructions with the mask.
+RT_DEV uint32_t sphere_bit(uint32_t m, f4v r, const RayCompact &y) {
+    float cq = __builtin_fmaf(r.z, y.m2oz, __builtin_fmaf(r.y, y.m2oy, __builtin_fmaf(r.x, y.m2ox, r.w + y.oo1)));
+    float bn = __builtin_fmaf(r.z, y.ndnz, __builtin_fmaf(r.y, y.ndny, __builtin_fmaf(r.x, y.ndnx, y.odn)));
+    float q = __builtin_fmaf(bn, bn, -cq);
+    return __builtin_amdgcn_alignbit(m, __float_as_uint(q), 31);
+}
+template <typename RayT>
+RT_DEV uint32_t group_bits(uint32_t m, const Rec4 &g, const RayT &y) {
+    m = sphere_bit(m, g.r0, y);
+    m = sphere_bit(m, g.r1, y);
+    m = sphere_bit(m, g.r2, y);
+    return sphere_bit(m, g.r3, y);
+}
+
+// Pass A over sphere groups [g0, g1): writes one candidate word per 32 spheres to masks[word * 64 + lane]
+// (sphere j of the word at bit 31 - j) and returns the bitmap of non-empty words.
+template <typename F, typename RayT>
+RT_DEV uint32_t filter_round(const F &f, int g0, int g1, uint32_t *masks, int lane, const RayT &y) {
+    uint32_t nz = 0;
+    int g = g0;
+    Rec4 A = f.load4(g);
+    for (int w = 0; g < g1; ++w) {
+        const int ng = min(kWordGroups, g1 - g);
+        uint32_t m = 0;
+        if (ng == kWordGroups) {
+#pragma unroll
+            for (int i = 0; i < kWordGroups; i += 2) {
+                f.settle(A);
+                Rec4 B = f.load4(g + i + 1);
+                m = group_bits(m, A, y);
+                f.settle(B);
+                A = f.load4(g + i + 2);  // the record arrays carry one spare group at the end
+                m = group_bits(m, B, y);
+            }
+        } else {
+            for (int i = 0; i < ng; ++i) {
+                f.settle(A);
+                Rec4 B = f.load4(g + i + 1);
+                m = group_bits(m, A, y);
+                A = B;
+            }
+        }
+        g += ng;
+        const uint32_t cand = (~m) << (32 - 4 * ng);
+        masks[w * 64 + lane] = cand;
+        nz |= (cand != 0u ? 1u : 0u) << w;
+    }
+    return nz;
+}
+
+// Closest sphere hit of ray (o, d) over all spheres: the sphere part of world_hit (Shaders.metal:13-32) with
+// hitSphere (Lib.metal:215-246).  Returns the sphere slot or -1; t in tbest.
+//
+// Conservativeness of pass A.  Let oc = o - c, a = d.d, b = oc.d, c = |oc|^2 - r^2 as the reference evaluates them
+// (uncontracted float), u = 2^-24.  Whenever the reference's discriminant b*b - a*c is >= 0, rounding analysis
+// gives b^2/a >= |oc|^2 - r^2 - 17 u |oc|^2 in exact arithmetic.
+//  General filter: evaluates the same difference with fused operations from dn = d (1 + 2^-18)/|d| (rsq, 1 ulp)
+//   with error <= ~17 u |oc|^2 + 4 u r^2.  The direction scale adds >= 64 u |oc|^2 of slack when |oc|^2 >= 2 r^2;
+//   the 2^-17 = 128 u inflation of r^2 covers |oc|^2 < 2 r^2 (needs <= 72 u r^2).  Margin >= 1.8x.
+//  Compact filter: the expanded form cancels terms of size S = |o|^2 + |c|^2: its own error is <= ~50 u S, the
+//   reference-side term is <= 34 u S, and it subtracts 2^-16 (S + r^2) = 256 u (S + r^2).  Margin >= 3x.  Because
+//   that slack grows with S, a wave uses the compact filter only while every lane's |o|^2 is below the
+//   scene-dependent oo_limit; the general filter is translation invariant and is the fallback.
+// The bounds assume operands in the normal float range with magnitudes below 2^60.  A NaN or infinity in q has
+// an unspecified sign bit; that is harmless because such operands cannot produce a finite root in pass B's
+// arithmetic either.
+template <typename F, bool PROF>
+RT_DEV int closest_sphere(const TraceParams &P, const F &fc, const F &fg, uint32_t *wave_masks, V3 o, V3 d, float &tbest,
+                          Prof<PROF> &prof) {
+    const float a = dot(d, d);
+    const bool a_ok = !(__builtin_fabsf(a) < 1e-6f);  // Lib.metal:226-228: such a ray hits no sphere
+    const float s = __builtin_amdgcn_rsqf(a) * kDirScale;
+    const V3 dn = v3(d.x * s, d.y * s, d.z * s);
+    const float oo = __builtin_fmaf(o.z, o.z, __builtin_fmaf(o.y, o.y, o.x * o.x));
+    const bool general = __builtin_amdgcn_ballot_w64(!(oo <= P.oo_limit)) != 0;  // wave-uniform
+    const int lane = threadIdx.x & 63;
+    int ibest = -1;
+    for (int g0 = 0; g0 < P.ngroups; g0 += kRoundWords * kWordGroups) {
+        const int g1 = min(P.ngroups, g0 + kRoundWords * kWordGroups);
+        uint32_t nz;
+        if (general) {
+            RayGeneral y = {o, dn};
+            nz = filter_round(fg, g0, g1, wave_masks, lane, y);
+        } else {
+            RayCompact y;
+            y.ndnx = -dn.x; y.ndny = -dn.y; y.ndnz = -dn.z;
+            y.odn = __builtin_fmaf(o.z, dn.z, __builtin_fmaf(o.y, dn.y, o.x * dn.x));
+            y.m2ox = -2.0f * o.x; y.m2oy = -2.0f * o.y; y.m2oz = -2.0f * o.z;
+            y.oo1 = oo * (1.0f - kCompactSlack);
+            nz = filter_round(fc, g0, g1, wave_masks, lane, y);
+        }
+        if (!a_ok) nz = 0;
+        prof.lap(1);
+        uint32_t m = 0;
+        int w = 0;
+        for (;;) {
+            if (m == 0) {
+                if (nz == 0) break;
+                w = __builtin_ctz(nz);
+                nz &= nz - 1;
+                m = wave_masks[w * 64 + lane];
+            }
+            const int j = __builtin_clz(m);
+            m &= ~(0x80000000u >> j);
+            const int k = 4 * g0 + w * 32 + j;
+            // Lib.metal:216-238 as written
+            f4v rec = fg.load1(k);
+            float radius = P.rad[k];
+            float ocx = o.x - rec.x, ocy = o.y - rec.y, ocz = o.z - rec.z;
+            float b = ocx * d.x + ocy * d.y + ocz * d.z;
+            float c = (ocx * ocx + ocy * ocy + ocz * ocz) - radius * radius;
+            float disc = b * b - a * c;
+            float root;
+            if (sphere_root(disc, b, a, tbest, root)) {
+                tbest = root;
+                ibest = k;
+            }
+        }
+        prof.lap(2);
+    }
+    return ibest;
+}
+
+// Closest hit over spheres and quads; fills hit and returns the object index or -1.
+template <typename F, bool PROF>
+RT_DEV int world_hit(const TraceParams &P, const F &fc, const F &fg, uint32_t *wave_masks, V3 o, V3 d, Hit &hit,
+                     float &t_out, Prof<PROF> &prof) {
+    float tbest = kMaxFloat;
+    int slot = closest_sphere(P, fc, fg, wave_masks, o, d, tbest, prof);
+    int obj = -1;
+    if (slot >= 0) {
+        obj = P.sph_obj[slot];
+        f4v s = fg.load1(slot);
+        float r = P.rad[slot];
+        hit.point = o + tbest * d;                                         // Lib.metal:241
+        V3 outward = (hit.point - v3(s.x, s.y, s.z)) / r;                  // Lib.metal:242
+        apply_normals(hit, d, outward);
+    }
+    for (int q = 0; q < P.nquad; ++q) {
+        QuadDev quad = P.quads[q];
+        float t;
+        V3 point, normal;
+        if (hit_quad(quad, o, d, tbest, t, point, normal)) {
+            // world_hit keeps a later object only when strictly closer (Shaders.metal:21); objects are
+            // visited here out of index order, so an equal distance goes to the lower index.
+            if (t < tbest || (t == tbest && obj >= 0 && quad.obj < obj)) {
+                tbest = t;
+                obj = quad.obj;
+                hit.point = point;
+                apply_normals(hit, d, normal);
+            }
+        }
+    }
+    t_out = tbest;
+    prof.lap(3);
+    return obj;
+}
+
+// The parameter block as it lies in the kernel argument segment, behind a pointer the optimiser cannot see
+// through: loads of the cold fields stay where they are written instead of being hoisted to kernel entry and
+// held in scalar registers across the sphere loop.
+RT_DEV const TraceParams *cold_params() {
+    const TraceParams *p = (const TraceParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+// Dynamic LDS layout: [candidate words: 4 waves x kMaskWordsPerWave][LDS_SCENE only: compact records, general
+// records, each 4 * (ngroups + 1) x 16 B].
+template <bool LDS_SCENE>
+RT_DEV void stage_scene(const TraceParams &P, uint32_t *lds_words, uint32_t *&wave_masks, Fetch<LDS_SCENE> &fc,
+                        Fetch<LDS_SCENE> &fg) {
+    wave_masks = lds_words + (threadIdx.x >> 6) * kMaskWordsPerWave;
+    if constexpr (LDS_SCENE) {
+        const int n = 4 * (P.ngroups + 1);
+        f4v *c = (f4v *)(lds_words + (blockDim.x >> 6) * kMaskWordsPerWave);
+        f4v *g = c + n;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            c[i] = ((const f4v *)P.sphc)[i];
+            g[i] = ((const f4v *)P.sphg)[i];
+        }
+        __syncthreads();
+        fc.p = c;
+        fg.p = g;
+    } else {
+        fc.p = (const_f4_ptr)(uintptr_t)P.sphc;
+        fc.g = (const f4v *)P.sphc;
+        fg.p = (const_f4_ptr)(uintptr_t)P.sphg;
+        fg.g = (const f4v *)P.sphg;
+    }
+}
+
+template <bool LDS_SCENE, bool PROF>
+__global__ __launch_bounds__(256) void trace_kernel(const TraceParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_words[];
+    uint32_t *wave_masks;
+    Fetch<LDS_SCENE> fc, fg;
+    stage_scene<LDS_SCENE>(P, lds_words, wave_masks, fc, fg);
+
+    bool alive = true;      // this lane still has, or may still draw, work
+    bool need_ray = true;   // the lane's current path is finished (or it has none yet)
+    bool have_item = false;
+    uint32_t px = 0, py = 0, chunk = 0;
+    int ray = 0, ray_end = 0;
+    V4 acc = v4(0, 0, 0, 0);
+    V3 o = v3(0, 0, 0), d = v3(0, 0, 0);
+    V4 thr = v4(1, 1, 1, 1), fin = v4(0, 0, 0, 0);
+    Seed seed = {0, 0};
+    int depth = 0;
+    uint32_t nseg = 0;
+    Prof<PROF> prof;
+    prof.start();
+
+    for (;;) {
+        prof.count(5);
+        // ---- (re)generate: finish items, draw new ones, start the next camera ray ------------------
+        if (__builtin_amdgcn_ballot_w64(alive && need_ray) != 0) {
+            const TraceParams *C = cold_params();
+            while (alive && need_ray) {
+                if (!have_item || ray >= ray_end) {
+                    if (have_item) {
+                        size_t p = (size_t)py * C->width + px;
+                        if (C->mode == kModeAccum) {
+                            C->planes[(size_t)chunk * ((size_t)C->width * C->height) + p] = make_float4(acc.x, acc.y, acc.z, acc.w);
+                        } else {
+                            // Shaders.metal:142-160
+                            float n = (float)C->spp_pass;
+                            V4 passAcc = v4(acc.x / n, acc.y / n, acc.z / n, acc.w / n);
+                            float4 e = C->target[p];
+                            V4 finalColor;
+                            if (C->pass == 0) {
+                                finalColor = passAcc;
+                            } else {
+                                float ex = e.x * e.x, ey = e.y * e.y, ez = e.z * e.z;
+                                float totalRaysSoFar = (float)(C->pass * C->spp_pass + C->spp_pass);
+                                float passWeight = n / totalRaysSoFar;
+                                finalColor.x = ex * (1.0f - passWeight) + passAcc.x * passWeight;
+                                finalColor.y = ey * (1.0f - passWeight) + passAcc.y * passWeight;
+                                finalColor.z = ez * (1.0f - passWeight) + passAcc.z * passWeight;
+                                finalColor.w = 1.0f;
+                            }
+                            V4 w = write_color(finalColor);
+                            C->target[p] = make_float4(w.x, w.y, w.z, w.w);
+                        }
+                        have_item = false;
+                    }
+                    uint32_t item = atomicAdd(C->counter, 1u);
+                    if (item >= C->nitems) {
+                        alive = false;
+                        break;
+                    }
+                    const uint32_t tile_pixels = (uint32_t)C->tileW * (uint32_t)C->tileH;
+                    chunk = item / tile_pixels;
+                    uint32_t pix = item - chunk * tile_pixels;
+                    uint32_t ty = pix / (uint32_t)C->tileW;
+                    px = (uint32_t)C->tileX + (pix - ty * (uint32_t)C->tileW);
+                    py = (uint32_t)C->tileY + ty;
+                    ray = C->ray_begin + (int)chunk * C->chunk;
+                    ray_end = min(ray + C->chunk, C->ray_end);
+                    acc = v4(0, 0, 0, 0);
+                    have_item = true;
+                    if (ray >= ray_end) continue;  // empty range: store zeros on the next trip
+                }
+                // Shaders.metal:121-132
+                seed = sample_seed(px, py, C->pass, ray);
+                ++ray;
+                get_ray((int)px, (int)py, C->cam, seed, d, o);
+                if (length(d) < 1e-6f || __builtin_isnan(d.x) || __builtin_isnan(d.y) || __builtin_isnan(d.z)) continue;
+                thr = v4(1, 1, 1, 1);
+                fin = v4(0, 0, 0, 0);
+                depth = 0;
+                if (P.maxDepth <= 0) continue;  // color_ray's loop body never runs: the sample is (0,0,0,0)
+                need_ray = false;
+            }
+        }
+        prof.lap(0);
+        if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
+        if (!alive) continue;
+
+        // ---- one segment: closest hit (Shaders.metal:38-47) ------------------------------------------
+        ++nseg;
+        Hit hit;
+        float t;
+        int obj = world_hit(P, fc, fg, wave_masks, o, d, hit, t, prof);
+        bool done;
+        if (obj < 0) {
+            fin = fin + thr * P.sky;                       // Shaders.metal:45
+            done = true;
+        } else {
+            MatDev m = P.mats[obj];
+            fin = fin + thr * m.emis;                      // Shaders.metal:51-56
+            V4 att;
+            if (!scatter(m, d, o, hit, att, seed)) {       // Shaders.metal:60-62
+                done = true;
+            } else {
+                thr = thr * att;                           // Shaders.metal:64-65
+                ++depth;
+                done = depth >= P.maxDepth;
+            }
+        }
+        if (done) {
+            // Shaders.metal:137-139
+            fin.x = clampf(fin.x, 0.0f, 10.0f);
+            fin.y = clampf(fin.y, 0.0f, 10.0f);
+            fin.z = clampf(fin.z, 0.0f, 10.0f);
+            acc = acc + fin;
+            need_ray = true;
+        }
+        prof.lap(4);
+    }
+
+    // segment counter: one atomic per wave
+    const TraceParams *C = cold_params();
+    uint64_t total = nseg;
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
+    if ((threadIdx.x & 63) == 0 && total) atomicAdd(C->seg_counter, (unsigned long long)total);
+    if constexpr (PROF) {
+        if ((threadIdx.x & 63) == 0)
+            for (int i = 0; i < 6; ++i) atomicAdd(C->seg_counter + 1 + i, (unsigned long long)prof.t[i]);
+    }
+}
+
+// First hit of sample (pass, rayIndex 0) per pixel: {t, nx, ny, nz} and the object index.
+__global__ __launch_bounds__(256) void first_hit_kernel(const TraceParams P, float4 *__restrict__ out4,
+                                                        int *__restrict__ ids) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_words[];
+    uint32_t *wave_masks;
+    Fetch<false> fc, fg;
+    stage_scene<false>(P, lds_words, wave_masks, fc, fg);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool inside = i < P.width * P.height;
+    if (!inside) i = 0;  // keep every lane in the wave-level votes of closest_sphere
+    uint32_t py = (uint32_t)i / (uint32_t)P.width, px = (uint32_t)i - py * (uint32_t)P.width;
+    Seed seed = sample_seed(px, py, P.pass, 0);
+    V3 o, d;
+    get_ray((int)px, (int)py, P.cam, seed, d, o);
+    Hit hit;
+    float t;
+    Prof<false> prof;
+    int obj = world_hit(P, fc, fg, wave_masks, o, d, hit, t, prof);
+    if (!inside) return;
+    if (obj >= 0) {
+        out4[i] = make_float4(t, hit.normal.x, hit.normal.y, hit.normal.z);
+    } else {
+        out4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    ids[i] = obj;
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------------
+
+static size_t trace_lds_bytes(const TraceParams &P, bool lds_scene) {
+    return (size_t)4 * kMaskWordsPerWave * sizeof(uint32_t) + (lds_scene ? (size_t)8 * (P.ngroups + 1) * sizeof(f4v) : 0);
+}
+
+hipError_t launch_trace(const TraceParams &P, bool lds_scene, bool profile, int blocks, hipStream_t stream) {
+    size_t lds = trace_lds_bytes(P, lds_scene);
+    if (profile) {
+        if (lds_scene)
+            hipLaunchKernelGGL((trace_kernel<true, true>), dim3(blocks), dim3(256), lds, stream, P);
+        else
+            hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(256), lds, stream, P);
+    } else if (lds_scene) {
+        hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(256), lds, stream, P);
+    } else {
+        hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(256), lds, stream, P);
+    }
+    return hipGetLastError();
+}
+
+int trace_blocks_per_cu(const TraceParams &P, bool lds_scene) {
+    int n = 0;
+    size_t lds = trace_lds_bytes(P, lds_scene);
+    hipError_t e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<true, false>, 256, lds)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<false, false>, 256, lds);
+    if (e != hipSuccess || n < 1) n = 1;
+    return n;
+}
+
+hipError_t launch_first_hit(const TraceParams &P, float4 *out4, int *ids, hipStream_t stream) {
+    int n = P.width * P.height;
+    hipLaunchKernelGGL(first_hit_kernel, dim3((n + 255) / 256), dim3(256), trace_lds_bytes(P, false), stream, P, out4, ids);
+    return hipGetLastError();
+}
+
+}  // namespace rt

@@ -20,7 +20,7 @@ static double now_s(void) {
 
 int main(int argc, char **argv) {
     const char *scene = "cover", *out = NULL;
-    int width = 1200, height = 675, spp = 100, depth = 50, passes = 0, chunk = -1, fetch = 0, stamps = 0, waves = 4;
+    int width = 1200, height = 675, spp = 100, depth = 50, passes = 0, chunk = -1, fetch = 0, stamps = 0, filter = 0, bpc = 0;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--scene") && i + 1 < argc) scene = argv[++i];
         else if (!strcmp(argv[i], "--width") && i + 1 < argc) width = atoi(argv[++i]);
@@ -31,7 +31,8 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--chunk") && i + 1 < argc) chunk = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--fetch") && i + 1 < argc) fetch = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--stamps")) stamps = 1;
-        else if (!strcmp(argv[i], "--waves") && i + 1 < argc) waves = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--filter") && i + 1 < argc) filter = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--blocks-per-cu") && i + 1 < argc) bpc = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
@@ -59,7 +60,8 @@ int main(int argc, char **argv) {
     if (chunk >= 0) rt_set_option(ctx, RT_OPT_CHUNK, chunk);
     rt_set_option(ctx, RT_OPT_SCENE_FETCH, fetch);
     if (stamps) rt_set_option(ctx, RT_OPT_KERNEL, 2);
-    rt_set_option(ctx, 6, waves);
+    rt_set_option(ctx, RT_OPT_FILTER, filter);
+    rt_set_option(ctx, RT_OPT_BLOCKS_PER_CU, bpc);
 
     double t0, t1;
     if (passes > 0) {
@@ -88,6 +90,7 @@ int main(int argc, char **argv) {
         struct rt_stats st;
         rt_last_stats(ctx, &st);
         double msamples = (double)width * height * spp * 1e-6;
+        printf("grid %d blocks x %d threads\n", st.grid_blocks, st.block_threads);
         printf("%s %dx%d %d spp depth %d: %.3f s wall, kernel %.3f ms, %.2f Msamples/s, %.2f segments/sample, "
                "%.2f TFLOP/s algorithmic (23 flop x %d objects x segments)\n",
                scene, width, height, spp, depth, t1 - t0, st.kernel_ms, msamples / (t1 - t0),
