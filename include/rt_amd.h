@@ -143,6 +143,13 @@ RT_API int rt_last_stats(rt_ctx *ctx, struct rt_stats *out);
  * values and stores the number written in *count.  Blocks until those launches have finished. */
 RT_API int rt_trace_times(rt_ctx *ctx, float *ms, int cap, int *count);
 
+/* No counterpart in the reference.  Self-test of the sphere filter that precedes the exact hit test: runs
+ * blocks x 256 x pairs_per_thread pseudo-random, mostly grazing ray/sphere pairs and reports out[0] pairs,
+ * out[1] pairs whose reference discriminant is >= 0, out[2] / out[3] pairs flagged by the general / compact
+ * filter, out[4] / out[5] pairs with discriminant >= 0 that the general / compact filter failed to flag.
+ * out[4] and out[5] must be 0: the filters may only over-report. */
+RT_API int rt_selftest_filter(rt_ctx *ctx, uint32_t seed, int blocks, int pairs_per_thread, uint64_t out[6]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,7 @@ AMD_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_option", "rt_get_option", "rt_set_target", "rt_clear",
     "rt_write_target", "rt_read_target", "rt_render_tile", "rt_present_bgra8", "rt_set_scene", "rt_render",
     "rt_accum_clear", "rt_accum_ptr", "rt_resolve", "rt_synchronize", "rt_first_hit", "rt_last_stats", "rt_trace_times",
+    "rt_selftest_filter",
 ]
 HOST_SYMBOLS = [
     "rt_material_default", "rt_material_lambertian", "rt_material_metal", "rt_material_dielectric", "rt_material_light",
@@ -130,6 +131,7 @@ def amd_lib():
         lib.rt_first_hit.argtypes = [vp, C.POINTER(Uniforms), vp, ip, vp, vp]
         lib.rt_last_stats.argtypes = [vp, C.POINTER(Stats)]
         lib.rt_trace_times.argtypes = [vp, vp, ip, C.POINTER(ip)]
+        lib.rt_selftest_filter.argtypes = [vp, C.c_uint32, ip, ip, vp]
         _amd = lib
     return _amd
 
@@ -430,6 +432,11 @@ class MetalRenderer:
         cnt = C.c_int()
         self._check(self._lib.rt_trace_times(self._ctx, buf, 64, C.byref(cnt)))
         return list(buf[:cnt.value])
+
+    def selftestFilter(self, seed=1, blocks=2048, pairs_per_thread=256):
+        out = (C.c_uint64 * 6)()
+        self._check(self._lib.rt_selftest_filter(self._ctx, seed, blocks, pairs_per_thread, out))
+        return dict(zip(["pairs", "reference", "general", "compact", "general_missed", "compact_missed"], list(out)))
 
     def renderImage(self, u, objs, n, chunk=None):
         """Whole image in one go: clear accumulation, trace u.sampleCount samples, resolve, read back."""

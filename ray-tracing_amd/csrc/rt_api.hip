@@ -601,6 +601,22 @@ RT_API int rt_last_stats(rt_ctx *ctx, rt_stats *out) {
     return RT_OK;
 }
 
+RT_API int rt_selftest_filter(rt_ctx *ctx, uint32_t seed, int blocks, int pairs_per_thread, uint64_t out[6]) {
+    if (!ctx || !out || blocks <= 0 || pairs_per_thread <= 0) return RT_ERR_INVALID;
+    Bind bind(ctx);
+    unsigned long long *dev = nullptr;
+    RT_HIP(hipMalloc((void **)&dev, 256));
+    hipError_t e = hipMemsetAsync(dev, 0, 256, ctx->stream);
+    if (e == hipSuccess) e = launch_filter_selftest(seed, blocks, pairs_per_thread, dev, ctx->stream);
+    unsigned long long host[6] = {0, 0, 0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(host, dev, sizeof host, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_selftest_filter", e);
+    for (int i = 0; i < 6; ++i) out[i] = host[i];
+    return RT_OK;
+}
+
 RT_API int rt_trace_times(rt_ctx *ctx, float *ms, int cap, int *count) {
     if (!ctx || !ms || !count || cap < 0) return RT_ERR_INVALID;
     Bind bind(ctx);

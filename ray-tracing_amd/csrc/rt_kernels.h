@@ -47,6 +47,8 @@ struct TraceParams {
 hipError_t launch_trace(const TraceParams &P, bool lds_scene, bool profile, int blocks, hipStream_t stream);
 int trace_blocks_per_cu(const TraceParams &P, bool lds_scene);
 hipError_t launch_first_hit(const TraceParams &P, float4 *out4, int *ids, hipStream_t stream);
+hipError_t launch_filter_selftest(uint32_t seed, int blocks, int pairs_per_thread, unsigned long long *out,
+                                  hipStream_t stream);
 hipError_t launch_fold(float4 *accum, const float4 *planes, int nplanes, int width, int height, int tileX, int tileY,
                        int tileW, int tileH, hipStream_t stream);
 hipError_t launch_resolve(float4 *target, const float4 *accum, int npix, int spp, hipStream_t stream);

@@ -451,7 +451,87 @@ __global__ __launch_bounds__(256) void first_hit_kernel(const TraceParams P, flo
     ids[i] = obj;
 }
 
+// Self-test of pass A's guarantee: for pseudo-random, mostly grazing (ray, sphere) pairs over a wide range of
+// scales, count pairs whose reference discriminant is >= 0 but which a filter fails to flag.  Both counts must
+// be zero.  out: [0] pairs, [1] reference candidates, [2] general-filter candidates, [3] compact-filter
+// candidates, [4] general misses, [5] compact misses.
+__global__ __launch_bounds__(256) void filter_selftest_kernel(uint32_t seed0, int pairs_per_thread,
+                                                              unsigned long long *out) {
+    uint32_t st = pcg_hash(seed0 ^ pcg_hash(blockIdx.x * 256u + threadIdx.x));
+    auto rnd = [&]() -> float { st = pcg_hash(st); return (float)(st >> 8) * (1.0f / 16777216.0f); };  // [0,1)
+    auto sym = [&]() -> float { return 2.0f * rnd() - 1.0f; };
+    unsigned long long n_ref = 0, n_gen = 0, n_cmp = 0, miss_gen = 0, miss_cmp = 0;
+    for (int it = 0; it < pairs_per_thread; ++it) {
+        const float S = __builtin_ldexpf(1.0f, (int)(rnd() * 20.0f) - 8);              // overall scale 2^-8 .. 2^11
+        const V3 c = v3(S * 16.0f * sym(), S * 16.0f * sym(), S * 16.0f * sym());
+        const float r = S * __builtin_ldexpf(1.0f + rnd(), -(int)(rnd() * 10.0f));     // radius S * 2^-9 .. 2S
+        V3 u = v3(sym(), sym(), sym());
+        float ul = length(u);
+        if (!(ul > 1e-3f)) continue;
+        u = u / ul;
+        const float D = r * __builtin_ldexpf(1.0f + rnd(), (int)(rnd() * 14.0f) - 3);  // distance r/8 .. 2048 r
+        const V3 o = c + D * u;
+        // a point near the silhouette: c + v * r * (1 + eps), v perpendicular to u
+        V3 w = v3(sym(), sym(), sym());
+        V3 v = cross(u, w);
+        float vl = length(v);
+        if (!(vl > 1e-3f)) continue;
+        v = v / vl;
+        const int ek = (int)(rnd() * 8.0f);
+        const float eps = (ek == 0 ? 0.0f : __builtin_ldexpf(1.0f, -24 + 3 * ek)) * (rnd() < 0.5f ? -1.0f : 1.0f);
+        const float along = (rnd() < 0.25f) ? 0.0f : sym() * r;                        // slide the target along the ray
+        const V3 target = c + (r * (1.0f + eps)) * v + along * u;
+        V3 d = target - o;
+        const float lam = __builtin_ldexpf(1.0f + rnd(), (int)(rnd() * 12.0f) - 6);    // non-unit directions too
+        d = lam * d;
+        if (rnd() < 0.3f) d = normalize(d);
+
+        // the reference's discriminant (Lib.metal:216-221)
+        const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
+        const float a = dot(d, d);
+        if (__builtin_fabsf(a) < 1e-6f || !(a < 1e30f)) continue;
+        const float b = ocx * d.x + ocy * d.y + ocz * d.z;
+        const float cc = (ocx * ocx + ocy * ocy + ocz * ocz) - r * r;
+        const float disc = b * b - a * cc;
+        const bool ref = !(disc < 0.0f) && !__builtin_isnan(disc);
+
+        // the filters, exactly as closest_sphere sets them up
+        const float s = __builtin_amdgcn_rsqf(a) * kDirScale;
+        const V3 dn = v3(d.x * s, d.y * s, d.z * s);
+        const float oo = __builtin_fmaf(o.z, o.z, __builtin_fmaf(o.y, o.y, o.x * o.x));
+        RayGeneral yg = {o, dn};
+        f4v rg = {c.x, c.y, c.z, (r * r) * (1.0f + 0x1p-17f)};
+        const bool gen = (sphere_bit(0u, rg, yg) & 1u) == 0u;
+        RayCompact yc;
+        yc.ndnx = -dn.x; yc.ndny = -dn.y; yc.ndnz = -dn.z;
+        yc.odn = __builtin_fmaf(o.z, dn.z, __builtin_fmaf(o.y, dn.y, o.x * dn.x));
+        yc.m2ox = -2.0f * o.x; yc.m2oy = -2.0f * o.y; yc.m2oz = -2.0f * o.z;
+        yc.oo1 = oo * (1.0f - kCompactSlack);
+        const double slack = (double)kCompactSlack;
+        const double ccd = (double)c.x * c.x + (double)c.y * c.y + (double)c.z * c.z;
+        const double kq = ccd * (1.0 - slack) - (double)(r * r) * (1.0 + slack);
+        f4v rc = {c.x, c.y, c.z, __double2float_rd(kq)};
+        const bool cmp = (sphere_bit(0u, rc, yc) & 1u) == 0u;
+
+        n_ref += ref; n_gen += gen; n_cmp += cmp;
+        miss_gen += (ref && !gen);
+        miss_cmp += (ref && !cmp);
+    }
+    atomicAdd(&out[0], (unsigned long long)pairs_per_thread);
+    atomicAdd(&out[1], n_ref);
+    atomicAdd(&out[2], n_gen);
+    atomicAdd(&out[3], n_cmp);
+    if (miss_gen) atomicAdd(&out[4], miss_gen);
+    if (miss_cmp) atomicAdd(&out[5], miss_cmp);
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------------
+
+hipError_t launch_filter_selftest(uint32_t seed, int blocks, int pairs_per_thread, unsigned long long *out,
+                                  hipStream_t stream) {
+    hipLaunchKernelGGL(filter_selftest_kernel, dim3(blocks), dim3(256), 0, stream, seed, pairs_per_thread, out);
+    return hipGetLastError();
+}
 
 static size_t trace_lds_bytes(const TraceParams &P, bool lds_scene) {
     return (size_t)4 * kMaskWordsPerWave * sizeof(uint32_t) + (lds_scene ? (size_t)8 * (P.ngroups + 1) * sizeof(f4v) : 0);
