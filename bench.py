@@ -38,6 +38,7 @@ def parse():
     p.add_argument("--fetch", type=int, default=0, help="0 spheres in LDS, 1 scalar cache")
     p.add_argument("--blocks-per-cu", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo is for rehearsing N > 1 on fewer GPUs")
     p.add_argument("--cpu-spp", type=int, default=64, help="spp of the sub-sampled CPU baseline run")
     p.add_argument("--cpu-stride", type=int, default=4, help="pixel stride of the sub-sampled CPU baseline run")
     return p.parse_args()
@@ -80,9 +81,16 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and local_rank >= ndev:
+        raise SystemExit("rank %d has no GPU of its own (%d visible)" % (local_rank, ndev))
+    local_rank = local_rank % ndev  # only reachable with --backend gloo: ranks share GPUs for a rehearsal
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import __graft_entry__ as ge
     rt = ge.load_package()
@@ -109,7 +117,12 @@ def main():
         r.accumClear(accum.data_ptr())
         r.render(u, None, 0, begin, end, accum.data_ptr())
         if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+            if args.backend == "nccl":
+                dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI, ordered after the trace on this stream
+            else:
+                host = accum.cpu()
+                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                accum.copy_(host)
         if rank == 0:
             r.resolve(spp, accum.data_ptr())
 
@@ -129,7 +142,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

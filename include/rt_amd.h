@@ -48,7 +48,8 @@ enum {
 /* Option keys for rt_set_option. */
 enum {
     RT_OPT_CHUNK = 1,       /* samples per work item of the batch path; 0 = all samples of a call in one
-                               item, which reproduces the reference's sequential per-pixel sum order */
+                               item, which reproduces the reference's sequential per-pixel sum order;
+                               -1 (default) = automatic, between 8 and 64 */
     RT_OPT_KERNEL = 3,      /* 0 = persistent megakernel; 2 = the same kernel with in-kernel cycle stamps per phase
                                (diagnostic, slower; fills rt_stats.phase_cycles) */
     RT_OPT_SCENE_FETCH = 4, /* where the sphere filter reads its records: 0 = staged in LDS once per workgroup and

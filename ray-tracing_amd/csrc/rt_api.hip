@@ -37,7 +37,6 @@ struct rt_ctx {
 
     // compact scene
     DevBuf<float4> sph, sphc;
-    DevBuf<float> rad;
     DevBuf<int> sph_obj;
     DevBuf<QuadDev> quads;
     DevBuf<MatDev> mats;
@@ -52,7 +51,7 @@ struct rt_ctx {
     unsigned long long times_read = 0;  // launches already reported by rt_trace_times
     bool stats_pending = false;
 
-    int opt_chunk = 64;
+    int opt_chunk = -1;
     int opt_kernel = 0;
     int opt_fetch = 0;
     int opt_blocks_per_cu = 0;
@@ -129,7 +128,6 @@ int upload(rt_ctx *ctx, DevBuf<T> &b, const std::vector<T> &h) {
 int upload_scene(rt_ctx *ctx, const Object *objs, int n) {
     if (n < 0 || (n > 0 && !objs)) return fail(ctx, RT_ERR_INVALID, "rt: bad object array");
     std::vector<float4> sph;
-    std::vector<float> rad;
     std::vector<int> sph_obj;
     std::vector<QuadDev> quads;
     std::vector<MatDev> mats((size_t)n);
@@ -151,10 +149,7 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n) {
         m.inv_ior = 1.0f / o.mat.refraction_index;  // Lib.metal:185
         mats[(size_t)i] = m;
         if (o.type == TYPE_SPHERE) {
-            // filter record: r*r inflated by 2^-17 (see closest_sphere in rt_kernels.hip)
-            sph.push_back(make_float4(o.s.center.x, o.s.center.y, o.s.center.z,
-                                      (o.s.radius * o.s.radius) * (1.0f + 0x1p-17f)));
-            rad.push_back(o.s.radius);
+            sph.push_back(make_float4(o.s.center.x, o.s.center.y, o.s.center.z, o.s.radius));  // strict record
             sph_obj.push_back(i);
         } else if (o.type == TYPE_QUAD) {
             QuadDev q;
@@ -189,16 +184,13 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n) {
         double lim = budget[k];  // 10th percentile: 90 % of the spheres keep their inflation below 25 %
         oo_limit = lim > 0.0 ? (float)std::min(lim, 1e30) : -1.0f;
     }
-    const float ninf = -std::numeric_limits<float>::infinity();
     while ((int)sph.size() < nslots) {
-        sph.push_back(make_float4(0.0f, 0.0f, 0.0f, ninf));                                       // q = -inf
+        sph.push_back(make_float4(0.0f, 0.0f, 0.0f, std::numeric_limits<float>::quiet_NaN()));    // never a hit
         sphc.push_back(make_float4(0.0f, 0.0f, 0.0f, std::numeric_limits<float>::infinity()));    // q = -inf
-        rad.push_back(std::numeric_limits<float>::quiet_NaN());
         sph_obj.push_back(-1);
     }
     RT_TRY(upload(ctx, ctx->sph, sph));
     RT_TRY(upload(ctx, ctx->sphc, sphc));
-    RT_TRY(upload(ctx, ctx->rad, rad));
     RT_TRY(upload(ctx, ctx->sph_obj, sph_obj));
     RT_TRY(upload(ctx, ctx->quads, quads));
     RT_TRY(upload(ctx, ctx->mats, mats));
@@ -238,11 +230,11 @@ void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
     P.sky = ld4(u->globalIllumation);
     P.sphg = ctx->sph.ptr;
     P.sphc = ctx->sphc.ptr;
-    P.rad = ctx->rad.ptr;
     P.sph_obj = ctx->sph_obj.ptr;
     P.quads = ctx->quads.ptr;
     P.mats = ctx->mats.ptr;
     P.ngroups = ctx->ngroups;
+    P.nsph = ctx->nsph;
     P.nquad = ctx->nquad;
     P.oo_limit = ctx->opt_filter == 1 ? -1.0f : ctx->oo_limit;
     P.width = ctx->width;
@@ -326,7 +318,6 @@ RT_API void rt_destroy(rt_ctx *ctx) {
     (void)hipFree(ctx->planes.ptr);
     (void)hipFree(ctx->sph.ptr);
     (void)hipFree(ctx->sphc.ptr);
-    (void)hipFree(ctx->rad.ptr);
     (void)hipFree(ctx->sph_obj.ptr);
     (void)hipFree(ctx->quads.ptr);
     (void)hipFree(ctx->mats.ptr);
@@ -345,7 +336,7 @@ RT_API int rt_set_option(rt_ctx *ctx, int key, int value) {
     if (!ctx) return RT_ERR_INVALID;
     switch (key) {
         case RT_OPT_CHUNK:
-            if (value < 0) return fail(ctx, RT_ERR_INVALID, "rt: chunk must be >= 0");
+            if (value < -1) return fail(ctx, RT_ERR_INVALID, "rt: chunk must be >= -1");
             ctx->opt_chunk = value;
             return RT_OK;
         case RT_OPT_KERNEL:
@@ -502,7 +493,11 @@ RT_API int rt_render(rt_ctx *ctx, const Uniforms *u, const Object *objs, int obj
     if (ray_end == ray_begin) return RT_OK;
 
     const int nrays = ray_end - ray_begin;
-    const int chunk = ctx->opt_chunk > 0 && ctx->opt_chunk < nrays ? ctx->opt_chunk : nrays;
+    // opt_chunk: > 0 as given, 0 = one item per pixel (the reference's sequential sum), < 0 = automatic: about 8
+    // items per pixel, between 8 and 64 samples each, so that short launches still balance at the tail
+    int chunk = ctx->opt_chunk;
+    if (chunk < 0) chunk = std::max(8, std::min(64, nrays / 8));
+    if (chunk == 0 || chunk > nrays) chunk = nrays;
     const int nchunks = (nrays + chunk - 1) / chunk;
     const unsigned long long nitems = (unsigned long long)u->tileWidth * u->tileHeight * nchunks;
     if (nitems > 0xF0000000ull) return fail(ctx, RT_ERR_TOO_LARGE, "rt: too many work items; raise RT_OPT_CHUNK");

@@ -16,13 +16,14 @@ enum { kModeAccum = 0, kModeProgressive = 1 };
 // it does not occupy registers during the sphere loop.
 struct TraceParams {
     // ---- hot ----
-    const float4 *sphg;     // [4*(ngroups+1)] general filter records (cx, cy, cz, r*r * (1 + 2^-17))
+    const float4 *sphg;     // [4*(ngroups+1)] strict records (cx, cy, cz, r): exact hit test and the general filter
+                            //                 (padding: r = NaN, which can never hit)
     const float4 *sphc;     // [4*(ngroups+1)] compact filter records (cx, cy, cz, |c|^2 * (1 - 2^-17) - r*r * (1 + 2^-17))
-    const float *rad;       // [4*(ngroups+1)] radius as given (padding: NaN, which can never hit)
     const int *sph_obj;     // [4*(ngroups+1)] object index of each sphere slot
     const QuadDev *quads;   // [nquad]
     const MatDev *mats;     // [nobj] indexed by object index
     int ngroups;            // sphere slots / 4 (slots are padded to a multiple of 4 with never-hit records)
+    int nsph;               // real spheres
     int nquad;
     float oo_limit;         // rays with |origin|^2 above this use the general filter (see rt_trace.hip)
     int maxDepth;           // Uniforms.maxRayDepth

@@ -32,6 +32,7 @@ constexpr int kMaskWordsPerWave = kRoundWords * 64;  // LDS words per wave: one 
 // on the host when the records are built: r*r * (1 + 2^-17) in the general records, and a slack of
 // kCompactSlack * (|o|^2 + |c|^2 + r^2) in the compact form, whose per-ray share is applied here.
 constexpr float kDirScale = 1.0f + 0x1p-18f;
+constexpr float kRadiusScale = 1.0f + 0x1p-17f;
 constexpr float kCompactSlack = 0x1p-16f;
 
 typedef const f4v __attribute__((address_space(4))) *const_f4_ptr;
@@ -92,11 +93,13 @@ struct Prof {
 struct RayGeneral { V3 o, dn; };                                          // dn = d * kDirScale / |d|
 struct RayCompact { float ndnx, ndny, ndnz, odn, m2ox, m2oy, m2oz, oo1; };  // -dn, o.dn, -2*o, |o|^2 * (1 - kCompactSlack)
 
-// General filter, record (c, r2q): q = (oc.dn)^2 - (|oc|^2 - r2q), oc = o - c.  11 instructions with the mask.
+// General filter on the strict record (c, r): q = (oc.dn)^2 - (|oc|^2 - r2q), oc = o - c, r2q = r*r * (1 + 2^-17).
+// 12 instructions with the mask.
 RT_DEV uint32_t sphere_bit(uint32_t m, f4v r, const RayGeneral &y) {
     float ocx = y.o.x - r.x, ocy = y.o.y - r.y, ocz = y.o.z - r.z;
     float bn = __builtin_fmaf(ocz, y.dn.z, __builtin_fmaf(ocy, y.dn.y, ocx * y.dn.x));
-    float cq = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, -r.w)));
+    float nr2q = (r.w * kRadiusScale) * -r.w;  // -(r*r)(1 + 2^-17) up to 2 ulp, covered by the margin
+    float cq = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, nr2q)));
     float q = __builtin_fmaf(bn, bn, -cq);
     return __builtin_amdgcn_alignbit(m, __float_as_uint(q), 31);  // (m << 1) | sign(q)
 }
@@ -119,7 +122,7 @@ RT_DEV uint32_t group_bits(uint32_t m, const Rec4 &g, const RayT &y) {
 // Pass A over sphere groups [g0, g1): writes one candidate word per 32 spheres to masks[word * 64 + lane]
 // (sphere j of the word at bit 31 - j) and returns the bitmap of non-empty words.
 template <typename F, typename RayT>
-RT_DEV uint32_t filter_round(const F &f, int g0, int g1, uint32_t *masks, int lane, const RayT &y) {
+RT_DEV uint32_t filter_round(const F &f, int g0, int g1, int nsph, uint32_t *masks, int lane, const RayT &y) {
     uint32_t nz = 0;
     int g = g0;
     Rec4 A = f.load4(g);
@@ -144,8 +147,11 @@ RT_DEV uint32_t filter_round(const F &f, int g0, int g1, uint32_t *masks, int la
                 A = B;
             }
         }
+        // keep only real spheres: the last group may hold up to three padding slots
+        const int nvalid = nsph - 4 * g;
+        const uint32_t valid = nvalid >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> nvalid);
         g += ng;
-        const uint32_t cand = (~m) << (32 - 4 * ng);
+        const uint32_t cand = ((~m) << (32 - 4 * ng)) & valid;
         masks[w * 64 + lane] = cand;
         nz |= (cand != 0u ? 1u : 0u) << w;
     }
@@ -159,6 +165,7 @@ RT_DEV uint32_t filter_round(const F &f, int g0, int g1, uint32_t *masks, int la
 // (uncontracted float), u = 2^-24.  Whenever the reference's discriminant b*b - a*c is >= 0, rounding analysis
 // gives b^2/a >= |oc|^2 - r^2 - 17 u |oc|^2 in exact arithmetic.
 //  General filter: evaluates the same difference with fused operations from dn = d (1 + 2^-18)/|d| (rsq, 1 ulp)
+//   and r2q = r (1 + 2^-17) r (two roundings)
 //   with error <= ~17 u |oc|^2 + 4 u r^2.  The direction scale adds >= 64 u |oc|^2 of slack when |oc|^2 >= 2 r^2;
 //   the 2^-17 = 128 u inflation of r^2 covers |oc|^2 < 2 r^2 (needs <= 72 u r^2).  Margin >= 1.8x.
 //  Compact filter: the expanded form cancels terms of size S = |o|^2 + |c|^2: its own error is <= ~50 u S, the
@@ -184,14 +191,14 @@ RT_DEV int closest_sphere(const TraceParams &P, const F &fc, const F &fg, uint32
         uint32_t nz;
         if (general) {
             RayGeneral y = {o, dn};
-            nz = filter_round(fg, g0, g1, wave_masks, lane, y);
+            nz = filter_round(fg, g0, g1, P.nsph, wave_masks, lane, y);
         } else {
             RayCompact y;
             y.ndnx = -dn.x; y.ndny = -dn.y; y.ndnz = -dn.z;
             y.odn = __builtin_fmaf(o.z, dn.z, __builtin_fmaf(o.y, dn.y, o.x * dn.x));
             y.m2ox = -2.0f * o.x; y.m2oy = -2.0f * o.y; y.m2oz = -2.0f * o.z;
             y.oo1 = oo * (1.0f - kCompactSlack);
-            nz = filter_round(fc, g0, g1, wave_masks, lane, y);
+            nz = filter_round(fc, g0, g1, P.nsph, wave_masks, lane, y);
         }
         if (!a_ok) nz = 0;
         prof.lap(1);
@@ -208,11 +215,10 @@ RT_DEV int closest_sphere(const TraceParams &P, const F &fc, const F &fg, uint32
             m &= ~(0x80000000u >> j);
             const int k = 4 * g0 + w * 32 + j;
             // Lib.metal:216-238 as written
-            f4v rec = fg.load1(k);
-            float radius = P.rad[k];
+            f4v rec = fg.load1(k);  // (center, radius)
             float ocx = o.x - rec.x, ocy = o.y - rec.y, ocz = o.z - rec.z;
             float b = ocx * d.x + ocy * d.y + ocz * d.z;
-            float c = (ocx * ocx + ocy * ocy + ocz * ocz) - radius * radius;
+            float c = (ocx * ocx + ocy * ocy + ocz * ocz) - rec.w * rec.w;
             float disc = b * b - a * c;
             float root;
             if (sphere_root(disc, b, a, tbest, root)) {
@@ -234,10 +240,9 @@ RT_DEV int world_hit(const TraceParams &P, const F &fc, const F &fg, uint32_t *w
     int obj = -1;
     if (slot >= 0) {
         obj = P.sph_obj[slot];
-        f4v s = fg.load1(slot);
-        float r = P.rad[slot];
+        f4v s = fg.load1(slot);  // (center, radius)
         hit.point = o + tbest * d;                                         // Lib.metal:241
-        V3 outward = (hit.point - v3(s.x, s.y, s.z)) / r;                  // Lib.metal:242
+        V3 outward = (hit.point - v3(s.x, s.y, s.z)) / s.w;                // Lib.metal:242
         apply_normals(hit, d, outward);
     }
     for (int q = 0; q < P.nquad; ++q) {
@@ -500,7 +505,7 @@ __global__ __launch_bounds__(256) void filter_selftest_kernel(uint32_t seed0, in
         const V3 dn = v3(d.x * s, d.y * s, d.z * s);
         const float oo = __builtin_fmaf(o.z, o.z, __builtin_fmaf(o.y, o.y, o.x * o.x));
         RayGeneral yg = {o, dn};
-        f4v rg = {c.x, c.y, c.z, (r * r) * (1.0f + 0x1p-17f)};
+        f4v rg = {c.x, c.y, c.z, r};
         const bool gen = (sphere_bit(0u, rg, yg) & 1u) == 0u;
         RayCompact yc;
         yc.ndnx = -dn.x; yc.ndny = -dn.y; yc.ndnz = -dn.z;
