@@ -161,7 +161,8 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n) {
     }
     const int nsph = (int)sph.size();
     const int ngroups = (nsph + 3) / 4;
-    const int nslots = 4 * (ngroups + 1);  // one spare group: the filter prefetches one group past the end
+    // read-ahead room: the staged/scalar fetchers read one group past the end, the streaming fetcher two tiles
+    const int nslots = (4 * ngroups + 127) / 128 * 128 + 256;
     // Compact filter records and the origin limit below which a ray may use them (rt_trace.hip, closest_sphere).
     std::vector<float4> sphc;
     std::vector<double> budget;
@@ -249,8 +250,9 @@ void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
 
 // Enqueue one trace launch (counter reset, events, kernel).
 int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
-    const bool lds_scene = ctx->opt_fetch == 0 && 4 * P.ngroups <= kMaxLdsSpheres;
-    int per_cu = ctx->opt_blocks_per_cu > 0 ? ctx->opt_blocks_per_cu : trace_blocks_per_cu(P, lds_scene);
+    // 0: staged in LDS when the scene fits, else streamed; 1: scalar cache; 2: streamed
+    const int kind = ctx->opt_fetch == 1 ? 1 : (ctx->opt_fetch == 0 && 4 * P.ngroups <= kMaxLdsSpheres) ? 0 : 2;
+    int per_cu = ctx->opt_blocks_per_cu > 0 ? ctx->opt_blocks_per_cu : trace_blocks_per_cu(P, kind);
     long long blocks = (long long)per_cu * ctx->num_cus;
     long long need = ((long long)P.nitems + 255) / 256;
     if (blocks > need) blocks = need;
@@ -258,7 +260,7 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
     RT_HIP(hipMemsetAsync(ctx->counters, 0, 256, ctx->stream));
     const int slot = (int)(ctx->launches % rt_ctx::kRing);
     RT_HIP(hipEventRecord(ctx->ev0[slot], ctx->stream));
-    RT_HIP(launch_trace(P, lds_scene, ctx->opt_kernel == 2, (int)blocks, ctx->stream));
+    RT_HIP(launch_trace(P, kind, ctx->opt_kernel == 2, (int)blocks, ctx->stream));
     RT_HIP(hipEventRecord(ctx->ev1[slot], ctx->stream));
     ctx->launches++;
     ctx->stats_pending = true;
@@ -344,7 +346,7 @@ RT_API int rt_set_option(rt_ctx *ctx, int key, int value) {
             ctx->opt_kernel = value;
             return RT_OK;
         case RT_OPT_SCENE_FETCH:
-            if (value != 0 && value != 1) return fail(ctx, RT_ERR_INVALID, "rt: scene fetch must be 0 or 1");
+            if (value < 0 || value > 2) return fail(ctx, RT_ERR_INVALID, "rt: scene fetch must be 0, 1 or 2");
             ctx->opt_fetch = value;
             return RT_OK;
         case RT_OPT_BLOCKS_PER_CU:

@@ -143,15 +143,31 @@ RT_DEV void apply_normals(Hit &h, V3 dir, V3 outward) {
     h.normal = h.front ? outward : -outward;
 }
 
-// Root selection of Lib.metal:230-238 against the interval (kTMin, tmax).  Returns true and the root.
-RT_DEV bool sphere_root(float disc, float b, float a, float tmax, float &root_out) {
+// Root selection of Lib.metal:230-238 against the interval (kTMin, tmax), for a > 0 (callers have excluded
+// |a| < 1e-6, and a = d.d is never negative).  Returns true and the root.
+// nbest is the numerator whose quotient by a is the current tmax (+inf while tmax is still MAXFLOAT).  Division
+// by a positive a is monotonic, so a numerator <= 0 gives a root <= 0 < kTMin and a numerator >= nbest gives a
+// root >= tmax: both fail the reference's strict interval test, and the division is skipped without changing
+// any decision.  On success nbest is updated.
+RT_DEV bool sphere_root(float disc, float b, float a, float tmax, float &nbest, float &root_out) {
     if (disc < 0.0f) return false;
     float sqrtd = __builtin_sqrtf(disc);
-    float root = (-b - sqrtd) / a;
-    if (!(kTMin < root && root < tmax)) {
-        root = (-b + sqrtd) / a;
-        if (!(kTMin < root && root < tmax)) return false;
+    float n = -b - sqrtd;
+    bool ok = false;
+    float root = 0.0f;
+    if (n > 0.0f && n < nbest) {
+        root = n / a;
+        ok = kTMin < root && root < tmax;
     }
+    if (!ok) {
+        n = -b + sqrtd;
+        if (n > 0.0f && n < nbest) {
+            root = n / a;
+            ok = kTMin < root && root < tmax;
+        }
+    }
+    if (!ok) return false;
+    nbest = n;
     root_out = root;
     return true;
 }
@@ -196,8 +212,12 @@ RT_DEV float reflectance(float cosine, float refraction_index) {
 // Lambertian keeps the reference's field order: the scattered ray's DIRECTION is the hit point and its
 // ORIGIN is normal + random unit vector (Lib.metal:164 initialises Ray{direction, origin} positionally).
 RT_DEV bool scatter(const MatDev &m, V3 &dir, V3 &origin, const Hit &hit, V4 &attenuation, Seed &seed) {
+    // Lambertian and metal both draw one random unit vector, and in both it is the first use of the seed in
+    // the branch (Lib.metal:158, 171), so one rejection loop serves the lanes of both kinds.
+    V3 unit = v3(0.0f, 0.0f, 0.0f);
+    if (m.type == 0 || m.type == 1) unit = random_unit_vec(seed);
     if (m.type == 0) {
-        V3 scatter_direction = hit.normal + random_unit_vec(seed);
+        V3 scatter_direction = hit.normal + unit;
         const float s = 1e-8f;
         if ((__builtin_fabsf(scatter_direction.x) < s) && (__builtin_fabsf(scatter_direction.y) < s) &&
             (__builtin_fabsf(scatter_direction.z) < s))
@@ -208,7 +228,7 @@ RT_DEV bool scatter(const MatDev &m, V3 &dir, V3 &origin, const Hit &hit, V4 &at
         return true;
     } else if (m.type == 1) {
         V3 reflected = reflect(dir, hit.normal);
-        reflected = normalize(reflected) + (m.fuzz * random_unit_vec(seed));
+        reflected = normalize(reflected) + (m.fuzz * unit);
         dir = normalize(reflected);
         origin = hit.point;
         attenuation = m.albedo;

@@ -16,10 +16,11 @@ enum { kModeAccum = 0, kModeProgressive = 1 };
 // it does not occupy registers during the sphere loop.
 struct TraceParams {
     // ---- hot ----
-    const float4 *sphg;     // [4*(ngroups+1)] strict records (cx, cy, cz, r): exact hit test and the general filter
+    const float4 *sphg;     // [nslots] strict records (cx, cy, cz, r): exact hit test and the general filter
                             //                 (padding: r = NaN, which can never hit)
-    const float4 *sphc;     // [4*(ngroups+1)] compact filter records (cx, cy, cz, |c|^2 * (1 - 2^-17) - r*r * (1 + 2^-17))
-    const int *sph_obj;     // [4*(ngroups+1)] object index of each sphere slot
+    const float4 *sphc;     // [nslots] compact filter records (cx, cy, cz, |c|^2 * (1 - 2^-17) - r*r * (1 + 2^-17))
+    const int *sph_obj;     // [nslots] object index of each sphere slot; nslots = 4 * ngroups rounded up to a
+                            //          multiple of 128, plus 256 spare never-hit slots (read-ahead of the fetchers)
     const QuadDev *quads;   // [nquad]
     const MatDev *mats;     // [nobj] indexed by object index
     int ngroups;            // sphere slots / 4 (slots are padded to a multiple of 4 with never-hit records)
@@ -45,8 +46,9 @@ struct TraceParams {
     int spp_pass;           // kModeProgressive: Uniforms.sampleCount
 };
 
-hipError_t launch_trace(const TraceParams &P, bool lds_scene, bool profile, int blocks, hipStream_t stream);
-int trace_blocks_per_cu(const TraceParams &P, bool lds_scene);
+// fetch_kind: 0 records staged in LDS per workgroup, 1 scalar cache, 2 streamed through per-wave LDS tiles
+hipError_t launch_trace(const TraceParams &P, int fetch_kind, bool profile, int blocks, hipStream_t stream);
+int trace_blocks_per_cu(const TraceParams &P, int fetch_kind);
 hipError_t launch_first_hit(const TraceParams &P, float4 *out4, int *ids, hipStream_t stream);
 hipError_t launch_filter_selftest(uint32_t seed, int blocks, int pairs_per_thread, unsigned long long *out,
                                   hipStream_t stream);

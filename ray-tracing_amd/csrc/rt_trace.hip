@@ -39,13 +39,35 @@ typedef const f4v __attribute__((address_space(4))) *const_f4_ptr;
 
 struct Rec4 { f4v r0, r1, r2, r3; };
 
-// Where pass A reads its records from.  g = generic pointer to the same array for the per-lane reads of pass B.
-template <bool LDS_SCENE>
+// Where pass A reads its records from.  All three kinds expose: start(general) -- choose the record array for
+// this closest-hit search; begin_word(group) -- called before each 32-sphere word; load4(group) / settle();
+// load1(slot) -- the strict record (center, radius) of one sphere for pass B and the hit record.
+enum { kFetchLds = 0, kFetchScalar = 1, kFetchStream = 2 };
+constexpr int kTileRecords = 128;  // kFetchStream: records per LDS tile (two tiles per wave)
+
+template <int KIND>
 struct Fetch;
+
 template <>
-struct Fetch<false> {  // scalar cache: uniform address -> s_load_dwordx16 into scalar registers
-    const_f4_ptr p;
-    const f4v *g;
+struct Fetch<kFetchLds> {  // both arrays staged once per workgroup in LDS, read with a wave-uniform address (broadcast)
+    const f4v *pc, *pg, *p;
+    RT_DEV void start(bool general) { p = general ? pg : pc; }
+    RT_DEV void begin_word(int) {}
+    RT_DEV Rec4 load4(int group) const {
+        const f4v *q = p + 4 * group;
+        Rec4 r = {q[0], q[1], q[2], q[3]};
+        return r;
+    }
+    RT_DEV void settle(Rec4 &) const {}
+    RT_DEV f4v load1(int k) const { return pg[k]; }
+};
+
+template <>
+struct Fetch<kFetchScalar> {  // scalar cache: uniform address -> s_load_dwordx16 into scalar registers
+    const_f4_ptr pc, pg, p;
+    const f4v *strict;
+    RT_DEV void start(bool general) { p = general ? pg : pc; }
+    RT_DEV void begin_word(int) {}
     RT_DEV Rec4 load4(int group) const {
         const_f4_ptr q = p + 4 * group;
         Rec4 r = {q[0], q[1], q[2], q[3]};
@@ -58,18 +80,47 @@ struct Fetch<false> {  // scalar cache: uniform address -> s_load_dwordx16 into 
     RT_DEV void settle(Rec4 &r) const {
         asm volatile("" : "+s"(r.r0), "+s"(r.r1), "+s"(r.r2), "+s"(r.r3)::"memory");
     }
-    RT_DEV f4v load1(int k) const { return g[k]; }
+    RT_DEV f4v load1(int k) const { return strict[k]; }
 };
+
+// Scenes too large for LDS: every wave streams the record array through its own pair of 128-record LDS tiles.
+// Each lane loads two records per tile from global memory (coalesced 16-byte loads, served by L2: all waves read
+// the same array) two tiles ahead of use, parks them in registers, and writes them to LDS one tile ahead; pass A
+// then broadcast-reads them like the staged kind.  No workgroup barrier is involved: a wave only reads what it
+// wrote itself, and LDS operations of one wave execute in order.
 template <>
-struct Fetch<true> {  // LDS: records staged once per workgroup, read with a wave-uniform address (broadcast)
-    const f4v *p;
+struct Fetch<kFetchStream> {
+    const f4v *gc, *gg, *src;
+    f4v *tile;  // this wave's 2 x kTileRecords records
+    f4v pre0, pre1;
+    int lane;
+    RT_DEV void start(bool general) {
+        src = general ? gg : gc;
+        tile[lane] = src[lane];
+        tile[64 + lane] = src[64 + lane];
+        pre0 = src[kTileRecords + lane];
+        pre1 = src[kTileRecords + 64 + lane];
+        __builtin_amdgcn_wave_barrier();
+    }
+    RT_DEV void begin_word(int group) {
+        if ((group & (kTileRecords / 4 - 1)) == 0) {
+            const int t = group / (kTileRecords / 4);
+            f4v *next = tile + ((t + 1) & 1) * kTileRecords;
+            next[lane] = pre0;
+            next[64 + lane] = pre1;
+            const f4v *ahead = src + (t + 2) * kTileRecords;  // the arrays carry two spare tiles at the end
+            pre0 = ahead[lane];
+            pre1 = ahead[64 + lane];
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
     RT_DEV Rec4 load4(int group) const {
-        const f4v *q = p + 4 * group;
+        const f4v *q = tile + ((group / (kTileRecords / 4)) & 1) * kTileRecords + (group & (kTileRecords / 4 - 1)) * 4;
         Rec4 r = {q[0], q[1], q[2], q[3]};
         return r;
     }
     RT_DEV void settle(Rec4 &) const {}
-    RT_DEV f4v load1(int k) const { return p[k]; }
+    RT_DEV f4v load1(int k) const { return gg[k]; }
 };
 
 // Optional in-kernel cycle stamps (diagnostic instantiation only): wave-level s_memtime differences summed
@@ -94,39 +145,43 @@ struct RayGeneral { V3 o, dn; };                                          // dn 
 struct RayCompact { float ndnx, ndny, ndnz, odn, m2ox, m2oy, m2oz, oo1; };  // -dn, o.dn, -2*o, |o|^2 * (1 - kCompactSlack)
 
 // General filter on the strict record (c, r): q = (oc.dn)^2 - (|oc|^2 - r2q), oc = o - c, r2q = r*r * (1 + 2^-17).
-// 12 instructions with the mask.
-RT_DEV uint32_t sphere_bit(uint32_t m, f4v r, const RayGeneral &y) {
+// 12 instructions per sphere with the mask update.
+RT_DEV float sphere_q(f4v r, const RayGeneral &y) {
     float ocx = y.o.x - r.x, ocy = y.o.y - r.y, ocz = y.o.z - r.z;
     float bn = __builtin_fmaf(ocz, y.dn.z, __builtin_fmaf(ocy, y.dn.y, ocx * y.dn.x));
     float nr2q = (r.w * kRadiusScale) * -r.w;  // -(r*r)(1 + 2^-17) up to 2 ulp, covered by the margin
     float cq = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, nr2q)));
-    float q = __builtin_fmaf(bn, bn, -cq);
-    return __builtin_amdgcn_alignbit(m, __float_as_uint(q), 31);  // (m << 1) | sign(q)
+    return __builtin_fmaf(bn, bn, -cq);
 }
 // Compact filter, record (c, kq): the same quantity expanded so that no per-sphere subtraction is needed,
-// bn = o.dn - c.dn and |oc|^2 - r2q - slack = |o|^2(1-k) - 2 o.c + kq.  9 instructions with the mask.
-RT_DEV uint32_t sphere_bit(uint32_t m, f4v r, const RayCompact &y) {
+// bn = o.dn - c.dn and |oc|^2 - r2q - slack = |o|^2(1-k) - 2 o.c + kq.  9 instructions with the mask update.
+RT_DEV float sphere_q(f4v r, const RayCompact &y) {
     float cq = __builtin_fmaf(r.z, y.m2oz, __builtin_fmaf(r.y, y.m2oy, __builtin_fmaf(r.x, y.m2ox, r.w + y.oo1)));
     float bn = __builtin_fmaf(r.z, y.ndnz, __builtin_fmaf(r.y, y.ndny, __builtin_fmaf(r.x, y.ndnx, y.odn)));
-    float q = __builtin_fmaf(bn, bn, -cq);
-    return __builtin_amdgcn_alignbit(m, __float_as_uint(q), 31);
+    return __builtin_fmaf(bn, bn, -cq);
 }
+// (m << 1) | sign(q): sphere results enter the candidate word from the right.
+RT_DEV uint32_t push_sign(uint32_t m, float q) { return __builtin_amdgcn_alignbit(m, __float_as_uint(q), 31); }
+template <typename RayT>
+RT_DEV uint32_t sphere_bit(uint32_t m, f4v r, const RayT &y) { return push_sign(m, sphere_q(r, y)); }
+// Four spheres: the four q chains are independent and are written side by side so that the scheduler can
+// interleave them; only the four mask updates are serial.
 template <typename RayT>
 RT_DEV uint32_t group_bits(uint32_t m, const Rec4 &g, const RayT &y) {
-    m = sphere_bit(m, g.r0, y);
-    m = sphere_bit(m, g.r1, y);
-    m = sphere_bit(m, g.r2, y);
-    return sphere_bit(m, g.r3, y);
+    float q0 = sphere_q(g.r0, y), q1 = sphere_q(g.r1, y), q2 = sphere_q(g.r2, y), q3 = sphere_q(g.r3, y);
+    return push_sign(push_sign(push_sign(push_sign(m, q0), q1), q2), q3);
 }
 
 // Pass A over sphere groups [g0, g1): writes one candidate word per 32 spheres to masks[word * 64 + lane]
 // (sphere j of the word at bit 31 - j) and returns the bitmap of non-empty words.
 template <typename F, typename RayT>
-RT_DEV uint32_t filter_round(const F &f, int g0, int g1, int nsph, uint32_t *masks, int lane, const RayT &y) {
+RT_DEV uint32_t filter_round(F &f, int g0, int g1, int nsph, uint32_t *masks, int lane, const RayT &y) {
     uint32_t nz = 0;
     int g = g0;
+    f.begin_word(g);
     Rec4 A = f.load4(g);
     for (int w = 0; g < g1; ++w) {
+        if (w) f.begin_word(g);
         const int ng = min(kWordGroups, g1 - g);
         uint32_t m = 0;
         if (ng == kWordGroups) {
@@ -159,7 +214,8 @@ RT_DEV uint32_t filter_round(const F &f, int g0, int g1, int nsph, uint32_t *mas
 }
 
 // Closest sphere hit of ray (o, d) over all spheres: the sphere part of world_hit (Shaders.metal:13-32) with
-// hitSphere (Lib.metal:215-246).  Returns the sphere slot or -1; t in tbest.
+// hitSphere (Lib.metal:215-246).  Returns the sphere slot or -1; t in tbest.  Must be called by all 64 lanes of the
+// wave (the streaming fetcher loads tiles cooperatively); lanes without a ray pass active = false and get -1.
 //
 // Conservativeness of pass A.  Let oc = o - c, a = d.d, b = oc.d, c = |oc|^2 - r^2 as the reference evaluates them
 // (uncontracted float), u = 2^-24.  Whenever the reference's discriminant b*b - a*c is >= 0, rounding analysis
@@ -176,31 +232,33 @@ RT_DEV uint32_t filter_round(const F &f, int g0, int g1, int nsph, uint32_t *mas
 // an unspecified sign bit; that is harmless because such operands cannot produce a finite root in pass B's
 // arithmetic either.
 template <typename F, bool PROF>
-RT_DEV int closest_sphere(const TraceParams &P, const F &fc, const F &fg, uint32_t *wave_masks, V3 o, V3 d, float &tbest,
+RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool active, V3 o, V3 d, float &tbest,
                           Prof<PROF> &prof) {
     const float a = dot(d, d);
     const bool a_ok = !(__builtin_fabsf(a) < 1e-6f);  // Lib.metal:226-228: such a ray hits no sphere
     const float s = __builtin_amdgcn_rsqf(a) * kDirScale;
     const V3 dn = v3(d.x * s, d.y * s, d.z * s);
     const float oo = __builtin_fmaf(o.z, o.z, __builtin_fmaf(o.y, o.y, o.x * o.x));
-    const bool general = __builtin_amdgcn_ballot_w64(!(oo <= P.oo_limit)) != 0;  // wave-uniform
+    const bool general = __builtin_amdgcn_ballot_w64(active && !(oo <= P.oo_limit)) != 0;  // wave-uniform
     const int lane = threadIdx.x & 63;
     int ibest = -1;
+    float nbest = __builtin_inff();  // numerator of the current closest root, see sphere_root
+    f.start(general);
     for (int g0 = 0; g0 < P.ngroups; g0 += kRoundWords * kWordGroups) {
         const int g1 = min(P.ngroups, g0 + kRoundWords * kWordGroups);
         uint32_t nz;
         if (general) {
             RayGeneral y = {o, dn};
-            nz = filter_round(fg, g0, g1, P.nsph, wave_masks, lane, y);
+            nz = filter_round(f, g0, g1, P.nsph, wave_masks, lane, y);
         } else {
             RayCompact y;
             y.ndnx = -dn.x; y.ndny = -dn.y; y.ndnz = -dn.z;
             y.odn = __builtin_fmaf(o.z, dn.z, __builtin_fmaf(o.y, dn.y, o.x * dn.x));
             y.m2ox = -2.0f * o.x; y.m2oy = -2.0f * o.y; y.m2oz = -2.0f * o.z;
             y.oo1 = oo * (1.0f - kCompactSlack);
-            nz = filter_round(fc, g0, g1, P.nsph, wave_masks, lane, y);
+            nz = filter_round(f, g0, g1, P.nsph, wave_masks, lane, y);
         }
-        if (!a_ok) nz = 0;
+        if (!a_ok || !active) nz = 0;
         prof.lap(1);
         uint32_t m = 0;
         int w = 0;
@@ -215,13 +273,13 @@ RT_DEV int closest_sphere(const TraceParams &P, const F &fc, const F &fg, uint32
             m &= ~(0x80000000u >> j);
             const int k = 4 * g0 + w * 32 + j;
             // Lib.metal:216-238 as written
-            f4v rec = fg.load1(k);  // (center, radius)
+            f4v rec = f.load1(k);  // (center, radius)
             float ocx = o.x - rec.x, ocy = o.y - rec.y, ocz = o.z - rec.z;
             float b = ocx * d.x + ocy * d.y + ocz * d.z;
             float c = (ocx * ocx + ocy * ocy + ocz * ocz) - rec.w * rec.w;
             float disc = b * b - a * c;
             float root;
-            if (sphere_root(disc, b, a, tbest, root)) {
+            if (sphere_root(disc, b, a, tbest, nbest, root)) {
                 tbest = root;
                 ibest = k;
             }
@@ -233,19 +291,19 @@ RT_DEV int closest_sphere(const TraceParams &P, const F &fc, const F &fg, uint32
 
 // Closest hit over spheres and quads; fills hit and returns the object index or -1.
 template <typename F, bool PROF>
-RT_DEV int world_hit(const TraceParams &P, const F &fc, const F &fg, uint32_t *wave_masks, V3 o, V3 d, Hit &hit,
-                     float &t_out, Prof<PROF> &prof) {
+RT_DEV int world_hit(const TraceParams &P, F &f, uint32_t *wave_masks, bool active, V3 o, V3 d, Hit &hit, float &t_out,
+                     Prof<PROF> &prof) {
     float tbest = kMaxFloat;
-    int slot = closest_sphere(P, fc, fg, wave_masks, o, d, tbest, prof);
+    int slot = closest_sphere(P, f, wave_masks, active, o, d, tbest, prof);
     int obj = -1;
     if (slot >= 0) {
         obj = P.sph_obj[slot];
-        f4v s = fg.load1(slot);  // (center, radius)
+        f4v s = f.load1(slot);  // (center, radius)
         hit.point = o + tbest * d;                                         // Lib.metal:241
         V3 outward = (hit.point - v3(s.x, s.y, s.z)) / s.w;                // Lib.metal:242
         apply_normals(hit, d, outward);
     }
-    for (int q = 0; q < P.nquad; ++q) {
+    for (int q = 0; active && q < P.nquad; ++q) {
         QuadDev quad = P.quads[q];
         float t;
         V3 point, normal;
@@ -274,37 +332,44 @@ RT_DEV const TraceParams *cold_params() {
     return p;
 }
 
-// Dynamic LDS layout: [candidate words: 4 waves x kMaskWordsPerWave][LDS_SCENE only: compact records, general
-// records, each 4 * (ngroups + 1) x 16 B].
-template <bool LDS_SCENE>
-RT_DEV void stage_scene(const TraceParams &P, uint32_t *lds_words, uint32_t *&wave_masks, Fetch<LDS_SCENE> &fc,
-                        Fetch<LDS_SCENE> &fg) {
-    wave_masks = lds_words + (threadIdx.x >> 6) * kMaskWordsPerWave;
-    if constexpr (LDS_SCENE) {
+// Dynamic LDS layout: [candidate words: 4 waves x kMaskWordsPerWave] then, by fetch kind,
+//   kFetchLds:    compact records, strict records, each 4 * (ngroups + 1) x 16 B, staged by the workgroup;
+//   kFetchStream: 4 waves x 2 tiles x kTileRecords x 16 B;
+//   kFetchScalar: nothing.
+template <int KIND>
+RT_DEV void stage_scene(const TraceParams &P, uint32_t *lds_words, uint32_t *&wave_masks, Fetch<KIND> &f) {
+    const int wave = threadIdx.x >> 6;
+    wave_masks = lds_words + wave * kMaskWordsPerWave;
+    uint32_t *after_masks = lds_words + (blockDim.x >> 6) * kMaskWordsPerWave;
+    if constexpr (KIND == kFetchLds) {
         const int n = 4 * (P.ngroups + 1);
-        f4v *c = (f4v *)(lds_words + (blockDim.x >> 6) * kMaskWordsPerWave);
+        f4v *c = (f4v *)after_masks;
         f4v *g = c + n;
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             c[i] = ((const f4v *)P.sphc)[i];
             g[i] = ((const f4v *)P.sphg)[i];
         }
         __syncthreads();
-        fc.p = c;
-        fg.p = g;
+        f.pc = c;
+        f.pg = g;
+    } else if constexpr (KIND == kFetchScalar) {
+        f.pc = (const_f4_ptr)(uintptr_t)P.sphc;
+        f.pg = (const_f4_ptr)(uintptr_t)P.sphg;
+        f.strict = (const f4v *)P.sphg;
     } else {
-        fc.p = (const_f4_ptr)(uintptr_t)P.sphc;
-        fc.g = (const f4v *)P.sphc;
-        fg.p = (const_f4_ptr)(uintptr_t)P.sphg;
-        fg.g = (const f4v *)P.sphg;
+        f.gc = (const f4v *)P.sphc;
+        f.gg = (const f4v *)P.sphg;
+        f.tile = (f4v *)after_masks + wave * 2 * kTileRecords;
+        f.lane = threadIdx.x & 63;
     }
 }
 
-template <bool LDS_SCENE, bool PROF>
+template <int KIND, bool PROF>
 __global__ __launch_bounds__(256) void trace_kernel(const TraceParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_words[];
     uint32_t *wave_masks;
-    Fetch<LDS_SCENE> fc, fg;
-    stage_scene<LDS_SCENE>(P, lds_words, wave_masks, fc, fg);
+    Fetch<KIND> fetch;
+    stage_scene<KIND>(P, lds_words, wave_masks, fetch);
 
     bool alive = true;      // this lane still has, or may still draw, work
     bool need_ray = true;   // the lane's current path is finished (or it has none yet)
@@ -384,36 +449,37 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceParams P) {
         }
         prof.lap(0);
         if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
-        if (!alive) continue;
 
-        // ---- one segment: closest hit (Shaders.metal:38-47) ------------------------------------------
-        ++nseg;
+        // ---- one segment: closest hit (Shaders.metal:38-47); every lane takes part, lanes without work idle ---
         Hit hit;
         float t;
-        int obj = world_hit(P, fc, fg, wave_masks, o, d, hit, t, prof);
-        bool done;
-        if (obj < 0) {
-            fin = fin + thr * P.sky;                       // Shaders.metal:45
-            done = true;
-        } else {
-            MatDev m = P.mats[obj];
-            fin = fin + thr * m.emis;                      // Shaders.metal:51-56
-            V4 att;
-            if (!scatter(m, d, o, hit, att, seed)) {       // Shaders.metal:60-62
+        int obj = world_hit(P, fetch, wave_masks, alive, o, d, hit, t, prof);
+        if (alive) {
+            ++nseg;
+            bool done;
+            if (obj < 0) {
+                fin = fin + thr * P.sky;                       // Shaders.metal:45
                 done = true;
             } else {
-                thr = thr * att;                           // Shaders.metal:64-65
-                ++depth;
-                done = depth >= P.maxDepth;
+                MatDev m = P.mats[obj];
+                fin = fin + thr * m.emis;                      // Shaders.metal:51-56
+                V4 att;
+                if (!scatter(m, d, o, hit, att, seed)) {       // Shaders.metal:60-62
+                    done = true;
+                } else {
+                    thr = thr * att;                           // Shaders.metal:64-65
+                    ++depth;
+                    done = depth >= P.maxDepth;
+                }
             }
-        }
-        if (done) {
-            // Shaders.metal:137-139
-            fin.x = clampf(fin.x, 0.0f, 10.0f);
-            fin.y = clampf(fin.y, 0.0f, 10.0f);
-            fin.z = clampf(fin.z, 0.0f, 10.0f);
-            acc = acc + fin;
-            need_ray = true;
+            if (done) {
+                // Shaders.metal:137-139
+                fin.x = clampf(fin.x, 0.0f, 10.0f);
+                fin.y = clampf(fin.y, 0.0f, 10.0f);
+                fin.z = clampf(fin.z, 0.0f, 10.0f);
+                acc = acc + fin;
+                need_ray = true;
+            }
         }
         prof.lap(4);
     }
@@ -434,8 +500,8 @@ __global__ __launch_bounds__(256) void first_hit_kernel(const TraceParams P, flo
                                                         int *__restrict__ ids) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_words[];
     uint32_t *wave_masks;
-    Fetch<false> fc, fg;
-    stage_scene<false>(P, lds_words, wave_masks, fc, fg);
+    Fetch<kFetchScalar> fetch;
+    stage_scene<kFetchScalar>(P, lds_words, wave_masks, fetch);
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool inside = i < P.width * P.height;
     if (!inside) i = 0;  // keep every lane in the wave-level votes of closest_sphere
@@ -446,7 +512,7 @@ __global__ __launch_bounds__(256) void first_hit_kernel(const TraceParams P, flo
     Hit hit;
     float t;
     Prof<false> prof;
-    int obj = world_hit(P, fc, fg, wave_masks, o, d, hit, t, prof);
+    int obj = world_hit(P, fetch, wave_masks, inside, o, d, hit, t, prof);
     if (!inside) return;
     if (obj >= 0) {
         out4[i] = make_float4(t, hit.normal.x, hit.normal.y, hit.normal.z);
@@ -538,37 +604,47 @@ hipError_t launch_filter_selftest(uint32_t seed, int blocks, int pairs_per_threa
     return hipGetLastError();
 }
 
-static size_t trace_lds_bytes(const TraceParams &P, bool lds_scene) {
-    return (size_t)4 * kMaskWordsPerWave * sizeof(uint32_t) + (lds_scene ? (size_t)8 * (P.ngroups + 1) * sizeof(f4v) : 0);
+static size_t trace_lds_bytes(const TraceParams &P, int kind) {
+    size_t bytes = (size_t)4 * kMaskWordsPerWave * sizeof(uint32_t);
+    if (kind == kFetchLds) bytes += (size_t)8 * (P.ngroups + 1) * sizeof(f4v);
+    if (kind == kFetchStream) bytes += (size_t)4 * 2 * kTileRecords * sizeof(f4v);
+    return bytes;
 }
 
-hipError_t launch_trace(const TraceParams &P, bool lds_scene, bool profile, int blocks, hipStream_t stream) {
-    size_t lds = trace_lds_bytes(P, lds_scene);
-    if (profile) {
-        if (lds_scene)
-            hipLaunchKernelGGL((trace_kernel<true, true>), dim3(blocks), dim3(256), lds, stream, P);
-        else
-            hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(256), lds, stream, P);
-    } else if (lds_scene) {
-        hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(256), lds, stream, P);
-    } else {
-        hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(256), lds, stream, P);
-    }
+template <int KIND>
+static hipError_t launch_trace_k(const TraceParams &P, bool profile, int blocks, hipStream_t stream) {
+    size_t lds = trace_lds_bytes(P, KIND);
+    if (profile)
+        hipLaunchKernelGGL((trace_kernel<KIND, true>), dim3(blocks), dim3(256), lds, stream, P);
+    else
+        hipLaunchKernelGGL((trace_kernel<KIND, false>), dim3(blocks), dim3(256), lds, stream, P);
     return hipGetLastError();
 }
 
-int trace_blocks_per_cu(const TraceParams &P, bool lds_scene) {
+hipError_t launch_trace(const TraceParams &P, int fetch_kind, bool profile, int blocks, hipStream_t stream) {
+    switch (fetch_kind) {
+        case kFetchLds: return launch_trace_k<kFetchLds>(P, profile, blocks, stream);
+        case kFetchScalar: return launch_trace_k<kFetchScalar>(P, profile, blocks, stream);
+        default: return launch_trace_k<kFetchStream>(P, profile, blocks, stream);
+    }
+}
+
+int trace_blocks_per_cu(const TraceParams &P, int fetch_kind) {
     int n = 0;
-    size_t lds = trace_lds_bytes(P, lds_scene);
-    hipError_t e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<true, false>, 256, lds)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<false, false>, 256, lds);
+    size_t lds = trace_lds_bytes(P, fetch_kind);
+    hipError_t e;
+    switch (fetch_kind) {
+        case kFetchLds: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<kFetchLds, false>, 256, lds); break;
+        case kFetchScalar: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<kFetchScalar, false>, 256, lds); break;
+        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<kFetchStream, false>, 256, lds); break;
+    }
     if (e != hipSuccess || n < 1) n = 1;
     return n;
 }
 
 hipError_t launch_first_hit(const TraceParams &P, float4 *out4, int *ids, hipStream_t stream) {
     int n = P.width * P.height;
-    hipLaunchKernelGGL(first_hit_kernel, dim3((n + 255) / 256), dim3(256), trace_lds_bytes(P, false), stream, P, out4, ids);
+    hipLaunchKernelGGL(first_hit_kernel, dim3((n + 255) / 256), dim3(256), trace_lds_bytes(P, kFetchScalar), stream, P, out4, ids);
     return hipGetLastError();
 }
 

@@ -287,9 +287,9 @@ def test_sphere_filter_never_misses_a_reference_candidate(rt, renderer):
         assert r["general"] <= r["compact"] < 2 * r["reference"]
 
 
-@pytest.mark.parametrize("opt,val", [("RT_OPT_FILTER", 1), ("RT_OPT_SCENE_FETCH", 1)])
+@pytest.mark.parametrize("opt,val", [("RT_OPT_FILTER", 1), ("RT_OPT_SCENE_FETCH", 1), ("RT_OPT_SCENE_FETCH", 2)])
 def test_kernel_variants_bit_exact(rt, oracle, renderer, opt, val):
-    """General-only filter and scalar-cache fetch give the same bits as the defaults."""
+    """General-only filter, scalar-cache fetch and streamed fetch give the same bits as the defaults."""
     strict(renderer, rt)
     w, h, spp = 240, 135, 16
     objs, n = rt.scene("cover")
