@@ -77,8 +77,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d: launch N > 1 with python -m torch.distributed.run "
+                         "--nproc-per-node N" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     ndev = torch.cuda.device_count()
@@ -132,6 +133,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:
+        # build the communicator before anything is timed, whatever --warmup says
+        dist.all_reduce(torch.zeros(1, device="cuda" if args.backend == "nccl" else "cpu"))
     for _ in range(args.warmup):
         step()
     fence()

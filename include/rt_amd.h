@@ -53,7 +53,7 @@ enum {
     RT_OPT_KERNEL = 3,      /* 0 = persistent megakernel; 2 = the same kernel with in-kernel cycle stamps per phase
                                (diagnostic, slower; fills rt_stats.phase_cycles) */
     RT_OPT_SCENE_FETCH = 4, /* where the sphere filter reads its records: 0 = staged in LDS once per workgroup and
-                               broadcast-read (default; scenes up to 1792 spheres, larger ones use 2),
+                               broadcast-read (default; scenes up to 1792 spheres, larger ones use 1),
                                1 = through the scalar cache into scalar registers,
                                2 = streamed from global memory through per-wave LDS tiles */
     RT_OPT_BLOCKS_PER_CU = 5, /* persistent grid size = this x compute units; 0 = occupancy query */
