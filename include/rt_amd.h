@@ -50,15 +50,18 @@ enum {
     RT_OPT_CHUNK = 1,       /* samples per work item of the batch path; 0 = all samples of a call in one
                                item, which reproduces the reference's sequential per-pixel sum order;
                                -1 (default) = automatic, between 8 and 64 */
-    RT_OPT_KERNEL = 3,      /* 0 = persistent megakernel; 2 = the same kernel with in-kernel cycle stamps per phase
-                               (diagnostic, slower; fills rt_stats.phase_cycles) */
+    RT_OPT_KERNEL = 3,      /* 0 = persistent kernel (default); 1 = wavefront formulation: generate / extend / shade
+                               kernels over a pool of path slots with compacted queues (same results; rt_render then
+                               returns only when the launch has finished); 2 = the persistent kernel with in-kernel
+                               cycle stamps per phase (diagnostic; fills rt_stats.phase_cycles) */
     RT_OPT_SCENE_FETCH = 4, /* where the sphere filter reads its records: 0 = staged in LDS once per workgroup and
                                broadcast-read (default; scenes up to 1792 spheres, larger ones use 1),
                                1 = through the scalar cache into scalar registers,
                                2 = streamed from global memory through per-wave LDS tiles */
     RT_OPT_BLOCKS_PER_CU = 5, /* persistent grid size = this x compute units; 0 = occupancy query */
-    RT_OPT_FILTER = 6       /* 0 = compact 9-instruction sphere filter where the scene allows it (default),
-                               1 = always the translation-invariant 11-instruction filter; results are identical */
+    RT_OPT_FILTER = 6,      /* 0 = compact 9-instruction sphere filter where the scene allows it (default),
+                               1 = always the translation-invariant 12-instruction filter; results are identical */
+    RT_OPT_WAVEFRONT_SLOTS = 7 /* path slots of the wavefront pool (default 2^20; 168 bytes of device memory each) */
 };
 
 /* setupMetal (ContentView.swift:328-356): device, queue, pipelines.  `device` is the HIP device ordinal.

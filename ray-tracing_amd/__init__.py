@@ -83,7 +83,7 @@ class Stats(C.Structure):
                 ("grid_blocks", C.c_int), ("block_threads", C.c_int), ("phase_cycles", C.c_uint64 * 6)]
 
 
-RT_OPT_CHUNK, RT_OPT_KERNEL, RT_OPT_SCENE_FETCH, RT_OPT_BLOCKS_PER_CU, RT_OPT_FILTER = 1, 3, 4, 5, 6
+RT_OPT_CHUNK, RT_OPT_KERNEL, RT_OPT_SCENE_FETCH, RT_OPT_BLOCKS_PER_CU, RT_OPT_FILTER, RT_OPT_WAVEFRONT_SLOTS = 1, 3, 4, 5, 6, 7
 
 # Every symbol include/rt_amd.h declares.
 AMD_SYMBOLS = [

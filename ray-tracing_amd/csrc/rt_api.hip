@@ -34,6 +34,7 @@ struct rt_ctx {
 
     int width = 0, height = 0;
     DevBuf<float4> target, accum, planes;
+    DevBuf<char> wf_pool;
 
     // compact scene
     DevBuf<float4> sph, sphc;
@@ -56,6 +57,7 @@ struct rt_ctx {
     int opt_fetch = 0;
     int opt_blocks_per_cu = 0;
     int opt_filter = 0;
+    int opt_wf_slots = 1 << 20;
 
     rt_stats last = {};
     std::string err;
@@ -260,9 +262,23 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
     if (blocks < 1) blocks = 1;
     RT_HIP(hipMemsetAsync(ctx->counters, 0, 256, ctx->stream));
     const int slot = (int)(ctx->launches % rt_ctx::kRing);
-    RT_HIP(hipEventRecord(ctx->ev0[slot], ctx->stream));
-    RT_HIP(launch_trace(P, kind, ctx->opt_kernel == 2, (int)blocks, ctx->stream));
-    RT_HIP(hipEventRecord(ctx->ev1[slot], ctx->stream));
+    if (ctx->opt_kernel == 1) {
+        // wavefront formulation: a pool of path slots, generate/extend/shade kernels per bounce step
+        if (ctx->width > 65535 || ctx->height > 65535)
+            return fail(ctx, RT_ERR_TOO_LARGE, "rt: the wavefront kernels pack pixel coordinates in 16 bits");
+        long long slots = ((long long)P.nitems + 255) / 256 * 256;
+        if (slots > ctx->opt_wf_slots) slots = ctx->opt_wf_slots;
+        RT_TRY(grow(ctx, ctx->wf_pool, wavefront_pool_alloc_bytes((int)slots)));
+        RT_HIP(hipEventRecord(ctx->ev0[slot], ctx->stream));
+        int steps = 0;
+        RT_HIP(run_wavefront(P, kind == 0 ? 0 : 1, ctx->wf_pool.ptr, (int)slots, 4 * ctx->num_cus, ctx->stream, &steps));
+        RT_HIP(hipEventRecord(ctx->ev1[slot], ctx->stream));
+        blocks = slots / 256;
+    } else {
+        RT_HIP(hipEventRecord(ctx->ev0[slot], ctx->stream));
+        RT_HIP(launch_trace(P, kind, ctx->opt_kernel == 2, (int)blocks, ctx->stream));
+        RT_HIP(hipEventRecord(ctx->ev1[slot], ctx->stream));
+    }
     ctx->launches++;
     ctx->stats_pending = true;
     ctx->last = {};
@@ -319,6 +335,7 @@ RT_API void rt_destroy(rt_ctx *ctx) {
     (void)hipFree(ctx->target.ptr);
     (void)hipFree(ctx->accum.ptr);
     (void)hipFree(ctx->planes.ptr);
+    (void)hipFree(ctx->wf_pool.ptr);
     (void)hipFree(ctx->sph.ptr);
     (void)hipFree(ctx->sphc.ptr);
     (void)hipFree(ctx->sph_obj.ptr);
@@ -343,7 +360,7 @@ RT_API int rt_set_option(rt_ctx *ctx, int key, int value) {
             ctx->opt_chunk = value;
             return RT_OK;
         case RT_OPT_KERNEL:
-            if (value != 0 && value != 2) return fail(ctx, RT_ERR_INVALID, "rt: kernel variant not available");
+            if (value < 0 || value > 2) return fail(ctx, RT_ERR_INVALID, "rt: kernel variant must be 0, 1 or 2");
             ctx->opt_kernel = value;
             return RT_OK;
         case RT_OPT_SCENE_FETCH:
@@ -358,6 +375,10 @@ RT_API int rt_set_option(rt_ctx *ctx, int key, int value) {
             if (value != 0 && value != 1) return fail(ctx, RT_ERR_INVALID, "rt: filter must be 0 or 1");
             ctx->opt_filter = value;
             return RT_OK;
+        case RT_OPT_WAVEFRONT_SLOTS:
+            if (value < 256 || value > (1 << 24)) return fail(ctx, RT_ERR_INVALID, "rt: wavefront slots out of range");
+            ctx->opt_wf_slots = value / 256 * 256;
+            return RT_OK;
     }
     return fail(ctx, RT_ERR_INVALID, "rt: unknown option");
 }
@@ -370,6 +391,7 @@ RT_API int rt_get_option(const rt_ctx *ctx, int key, int *value) {
         case RT_OPT_SCENE_FETCH: *value = ctx->opt_fetch; return RT_OK;
         case RT_OPT_BLOCKS_PER_CU: *value = ctx->opt_blocks_per_cu; return RT_OK;
         case RT_OPT_FILTER: *value = ctx->opt_filter; return RT_OK;
+        case RT_OPT_WAVEFRONT_SLOTS: *value = ctx->opt_wf_slots; return RT_OK;
     }
     return RT_ERR_INVALID;
 }

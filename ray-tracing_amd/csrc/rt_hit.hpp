@@ -1,0 +1,355 @@
+// rt_hit.hpp -- the closest-hit search shared by the persistent kernel (rt_trace.hip) and the wavefront kernels
+// (rt_wavefront.hip): record fetchers, the conservative sphere filter (pass A), the exact resolve (pass B), quads,
+// and the hit record.  Restates world_hit / hitObject / hitSphere / hitPlane of the reference
+// (reference: "Ray Tracer/Shaders.metal":13-32, "Ray Tracer/Lib.metal":215-291).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_device.hpp"
+#include "rt_kernels.h"
+
+namespace rt {
+
+constexpr int kWordGroups = 8;    // groups of 4 spheres per 32-bit candidate word
+constexpr int kRoundWords = 16;   // candidate words per resolve round (512 spheres)
+constexpr int kMaskWordsPerWave = kRoundWords * 64;  // LDS words per wave: one word per lane per round word
+
+// Filter margins (see closest_sphere).  kDirScale inflates the b side of both filters; the c side is inflated
+// on the host when the records are built: r*r * (1 + 2^-17) in the general records, and a slack of
+// kCompactSlack * (|o|^2 + |c|^2 + r^2) in the compact form, whose per-ray share is applied here.
+constexpr float kDirScale = 1.0f + 0x1p-18f;
+constexpr float kRadiusScale = 1.0f + 0x1p-17f;
+constexpr float kCompactSlack = 0x1p-16f;
+
+typedef const f4v __attribute__((address_space(4))) *const_f4_ptr;
+
+struct Rec4 { f4v r0, r1, r2, r3; };
+
+// Where pass A reads its records from.  All three kinds expose: start(general) -- choose the record array for
+// this closest-hit search; begin_word(group) -- called before each 32-sphere word; load4(group) / settle();
+// load1(slot) -- the strict record (center, radius) of one sphere for pass B and the hit record.
+enum { kFetchLds = 0, kFetchScalar = 1, kFetchStream = 2 };
+constexpr int kTileRecords = 128;  // kFetchStream: records per LDS tile (two tiles per wave)
+
+template <int KIND>
+struct Fetch;
+
+template <>
+struct Fetch<kFetchLds> {  // both arrays staged once per workgroup in LDS, read with a wave-uniform address (broadcast)
+    const f4v *pc, *pg, *p;
+    RT_DEV void start(bool general) { p = general ? pg : pc; }
+    RT_DEV void begin_word(int) {}
+    RT_DEV Rec4 load4(int group) const {
+        const f4v *q = p + 4 * group;
+        Rec4 r = {q[0], q[1], q[2], q[3]};
+        return r;
+    }
+    RT_DEV void settle(Rec4 &) const {}
+    RT_DEV f4v load1(int k) const { return pg[k]; }
+};
+
+template <>
+struct Fetch<kFetchScalar> {  // scalar cache: uniform address -> s_load_dwordx16 into scalar registers
+    const_f4_ptr pc, pg, p;
+    const f4v *strict;
+    RT_DEV void start(bool general) { p = general ? pg : pc; }
+    RT_DEV void begin_word(int) {}
+    RT_DEV Rec4 load4(int group) const {
+        const_f4_ptr q = p + 4 * group;
+        Rec4 r = {q[0], q[1], q[2], q[3]};
+        return r;
+    }
+    // Scalar loads return out of order, so the only wait is "all of them".  Forcing that wait here, before the
+    // next group's load is issued, keeps exactly one group in flight behind the one being computed on.
+    // The records pass through the statement as read-write operands so that the arithmetic on them cannot be
+    // scheduled above it.
+    RT_DEV void settle(Rec4 &r) const {
+        asm volatile("" : "+s"(r.r0), "+s"(r.r1), "+s"(r.r2), "+s"(r.r3)::"memory");
+    }
+    RT_DEV f4v load1(int k) const { return strict[k]; }
+};
+
+// Scenes too large for LDS: every wave streams the record array through its own pair of 128-record LDS tiles.
+// Each lane loads two records per tile from global memory (coalesced 16-byte loads, served by L2: all waves read
+// the same array) two tiles ahead of use, parks them in registers, and writes them to LDS one tile ahead; pass A
+// then broadcast-reads them like the staged kind.  No workgroup barrier is involved: a wave only reads what it
+// wrote itself, and LDS operations of one wave execute in order.
+template <>
+struct Fetch<kFetchStream> {
+    const f4v *gc, *gg, *src;
+    f4v *tile;  // this wave's 2 x kTileRecords records
+    f4v pre0, pre1;
+    int lane;
+    RT_DEV void start(bool general) {
+        src = general ? gg : gc;
+        tile[lane] = src[lane];
+        tile[64 + lane] = src[64 + lane];
+        pre0 = src[kTileRecords + lane];
+        pre1 = src[kTileRecords + 64 + lane];
+        __builtin_amdgcn_wave_barrier();
+    }
+    RT_DEV void begin_word(int group) {
+        if ((group & (kTileRecords / 4 - 1)) == 0) {
+            const int t = group / (kTileRecords / 4);
+            f4v *next = tile + ((t + 1) & 1) * kTileRecords;
+            next[lane] = pre0;
+            next[64 + lane] = pre1;
+            const f4v *ahead = src + (t + 2) * kTileRecords;  // the arrays carry two spare tiles at the end
+            pre0 = ahead[lane];
+            pre1 = ahead[64 + lane];
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    RT_DEV Rec4 load4(int group) const {
+        const f4v *q = tile + ((group / (kTileRecords / 4)) & 1) * kTileRecords + (group & (kTileRecords / 4 - 1)) * 4;
+        Rec4 r = {q[0], q[1], q[2], q[3]};
+        return r;
+    }
+    RT_DEV void settle(Rec4 &) const {}
+    RT_DEV f4v load1(int k) const { return gg[k]; }
+};
+
+// Optional in-kernel cycle stamps (diagnostic instantiation only): wave-level s_memtime differences summed
+// per phase.  With PROF = false every member function is empty and nothing is emitted.
+template <bool PROF>
+struct Prof {
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};  // 0 regenerate, 1 filter pass, 2 resolve pass, 3 quads+hit record, 4 shade, 5 trips
+    uint64_t last = 0;
+    RT_DEV void start() { if constexpr (PROF) last = __builtin_amdgcn_s_memtime(); }
+    RT_DEV void lap(int i) {
+        if constexpr (PROF) {
+            uint64_t now = __builtin_amdgcn_s_memtime();
+            t[i] += now - last;
+            last = now;
+        }
+    }
+    RT_DEV void count(int i) { if constexpr (PROF) t[i] += 1; }
+};
+
+// Per-ray constants of the two filters.
+struct RayGeneral { V3 o, dn; };                                          // dn = d * kDirScale / |d|
+struct RayCompact { float ndnx, ndny, ndnz, odn, m2ox, m2oy, m2oz, oo1; };  // -dn, o.dn, -2*o, |o|^2 * (1 - kCompactSlack)
+
+// General filter on the strict record (c, r): q = (oc.dn)^2 - (|oc|^2 - r2q), oc = o - c, r2q = r*r * (1 + 2^-17).
+// 12 instructions per sphere with the mask update.
+RT_DEV float sphere_q(f4v r, const RayGeneral &y) {
+    float ocx = y.o.x - r.x, ocy = y.o.y - r.y, ocz = y.o.z - r.z;
+    float bn = __builtin_fmaf(ocz, y.dn.z, __builtin_fmaf(ocy, y.dn.y, ocx * y.dn.x));
+    float nr2q = (r.w * kRadiusScale) * -r.w;  // -(r*r)(1 + 2^-17) up to 2 ulp, covered by the margin
+    float cq = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, nr2q)));
+    return __builtin_fmaf(bn, bn, -cq);
+}
+// Compact filter, record (c, kq): the same quantity expanded so that no per-sphere subtraction is needed,
+// bn = o.dn - c.dn and |oc|^2 - r2q - slack = |o|^2(1-k) - 2 o.c + kq.  9 instructions with the mask update.
+RT_DEV float sphere_q(f4v r, const RayCompact &y) {
+    float cq = __builtin_fmaf(r.z, y.m2oz, __builtin_fmaf(r.y, y.m2oy, __builtin_fmaf(r.x, y.m2ox, r.w + y.oo1)));
+    float bn = __builtin_fmaf(r.z, y.ndnz, __builtin_fmaf(r.y, y.ndny, __builtin_fmaf(r.x, y.ndnx, y.odn)));
+    return __builtin_fmaf(bn, bn, -cq);
+}
+// (m << 1) | sign(q): sphere results enter the candidate word from the right.
+RT_DEV uint32_t push_sign(uint32_t m, float q) { return __builtin_amdgcn_alignbit(m, __float_as_uint(q), 31); }
+template <typename RayT>
+RT_DEV uint32_t sphere_bit(uint32_t m, f4v r, const RayT &y) { return push_sign(m, sphere_q(r, y)); }
+// Four spheres: the four q chains are independent and are written side by side so that the scheduler can
+// interleave them; only the four mask updates are serial.
+template <typename RayT>
+RT_DEV uint32_t group_bits(uint32_t m, const Rec4 &g, const RayT &y) {
+    float q0 = sphere_q(g.r0, y), q1 = sphere_q(g.r1, y), q2 = sphere_q(g.r2, y), q3 = sphere_q(g.r3, y);
+    return push_sign(push_sign(push_sign(push_sign(m, q0), q1), q2), q3);
+}
+
+// Pass A over sphere groups [g0, g1): writes one candidate word per 32 spheres to masks[word * 64 + lane]
+// (sphere j of the word at bit 31 - j) and returns the bitmap of non-empty words.
+template <typename F, typename RayT>
+RT_DEV uint32_t filter_round(F &f, int g0, int g1, int nsph, uint32_t *masks, int lane, const RayT &y) {
+    uint32_t nz = 0;
+    int g = g0;
+    f.begin_word(g);
+    Rec4 A = f.load4(g);
+    for (int w = 0; g < g1; ++w) {
+        if (w) f.begin_word(g);
+        const int ng = min(kWordGroups, g1 - g);
+        uint32_t m = 0;
+        if (ng == kWordGroups) {
+#pragma unroll
+            for (int i = 0; i < kWordGroups; i += 2) {
+                f.settle(A);
+                Rec4 B = f.load4(g + i + 1);
+                m = group_bits(m, A, y);
+                f.settle(B);
+                A = f.load4(g + i + 2);  // the record arrays carry one spare group at the end
+                m = group_bits(m, B, y);
+            }
+        } else {
+            for (int i = 0; i < ng; ++i) {
+                f.settle(A);
+                Rec4 B = f.load4(g + i + 1);
+                m = group_bits(m, A, y);
+                A = B;
+            }
+        }
+        // keep only real spheres: the last group may hold up to three padding slots
+        const int nvalid = nsph - 4 * g;
+        const uint32_t valid = nvalid >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> nvalid);
+        g += ng;
+        const uint32_t cand = ((~m) << (32 - 4 * ng)) & valid;
+        masks[w * 64 + lane] = cand;
+        nz |= (cand != 0u ? 1u : 0u) << w;
+    }
+    return nz;
+}
+
+// Closest sphere hit of ray (o, d) over all spheres: the sphere part of world_hit (Shaders.metal:13-32) with
+// hitSphere (Lib.metal:215-246).  Returns the sphere slot or -1; t in tbest.  Must be called by all 64 lanes of the
+// wave (the streaming fetcher loads tiles cooperatively); lanes without a ray pass active = false and get -1.
+//
+// Conservativeness of pass A.  Let oc = o - c, a = d.d, b = oc.d, c = |oc|^2 - r^2 as the reference evaluates them
+// (uncontracted float), u = 2^-24.  Whenever the reference's discriminant b*b - a*c is >= 0, rounding analysis
+// gives b^2/a >= |oc|^2 - r^2 - 17 u |oc|^2 in exact arithmetic.
+//  General filter: evaluates the same difference with fused operations from dn = d (1 + 2^-18)/|d| (rsq, 1 ulp)
+//   and r2q = r (1 + 2^-17) r (two roundings)
+//   with error <= ~17 u |oc|^2 + 4 u r^2.  The direction scale adds >= 64 u |oc|^2 of slack when |oc|^2 >= 2 r^2;
+//   the 2^-17 = 128 u inflation of r^2 covers |oc|^2 < 2 r^2 (needs <= 72 u r^2).  Margin >= 1.8x.
+//  Compact filter: the expanded form cancels terms of size S = |o|^2 + |c|^2: its own error is <= ~50 u S, the
+//   reference-side term is <= 34 u S, and it subtracts 2^-16 (S + r^2) = 256 u (S + r^2).  Margin >= 3x.  Because
+//   that slack grows with S, a wave uses the compact filter only while every lane's |o|^2 is below the
+//   scene-dependent oo_limit; the general filter is translation invariant and is the fallback.
+// The bounds assume operands in the normal float range with magnitudes below 2^60.  A NaN or infinity in q has
+// an unspecified sign bit; that is harmless because such operands cannot produce a finite root in pass B's
+// arithmetic either.
+template <typename F, bool PROF>
+RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool active, V3 o, V3 d, float &tbest,
+                          Prof<PROF> &prof) {
+    const float a = dot(d, d);
+    const bool a_ok = !(__builtin_fabsf(a) < 1e-6f);  // Lib.metal:226-228: such a ray hits no sphere
+    const float s = __builtin_amdgcn_rsqf(a) * kDirScale;
+    const V3 dn = v3(d.x * s, d.y * s, d.z * s);
+    const float oo = __builtin_fmaf(o.z, o.z, __builtin_fmaf(o.y, o.y, o.x * o.x));
+    const bool general = __builtin_amdgcn_ballot_w64(active && !(oo <= P.oo_limit)) != 0;  // wave-uniform
+    const int lane = threadIdx.x & 63;
+    int ibest = -1;
+    float nbest = __builtin_inff();  // numerator of the current closest root, see sphere_root
+    f.start(general);
+    for (int g0 = 0; g0 < P.ngroups; g0 += kRoundWords * kWordGroups) {
+        const int g1 = min(P.ngroups, g0 + kRoundWords * kWordGroups);
+        uint32_t nz;
+        if (general) {
+            RayGeneral y = {o, dn};
+            nz = filter_round(f, g0, g1, P.nsph, wave_masks, lane, y);
+        } else {
+            RayCompact y;
+            y.ndnx = -dn.x; y.ndny = -dn.y; y.ndnz = -dn.z;
+            y.odn = __builtin_fmaf(o.z, dn.z, __builtin_fmaf(o.y, dn.y, o.x * dn.x));
+            y.m2ox = -2.0f * o.x; y.m2oy = -2.0f * o.y; y.m2oz = -2.0f * o.z;
+            y.oo1 = oo * (1.0f - kCompactSlack);
+            nz = filter_round(f, g0, g1, P.nsph, wave_masks, lane, y);
+        }
+        if (!a_ok || !active) nz = 0;
+        prof.lap(1);
+        uint32_t m = 0;
+        int w = 0;
+        for (;;) {
+            if (m == 0) {
+                if (nz == 0) break;
+                w = __builtin_ctz(nz);
+                nz &= nz - 1;
+                m = wave_masks[w * 64 + lane];
+            }
+            const int j = __builtin_clz(m);
+            m &= ~(0x80000000u >> j);
+            const int k = 4 * g0 + w * 32 + j;
+            // Lib.metal:216-238 as written
+            f4v rec = f.load1(k);  // (center, radius)
+            float ocx = o.x - rec.x, ocy = o.y - rec.y, ocz = o.z - rec.z;
+            float b = ocx * d.x + ocy * d.y + ocz * d.z;
+            float c = (ocx * ocx + ocy * ocy + ocz * ocz) - rec.w * rec.w;
+            float disc = b * b - a * c;
+            float root;
+            if (sphere_root(disc, b, a, tbest, nbest, root)) {
+                tbest = root;
+                ibest = k;
+            }
+        }
+        prof.lap(2);
+    }
+    return ibest;
+}
+
+// Closest hit over spheres and quads; fills hit and returns the object index or -1.
+template <typename F, bool PROF>
+RT_DEV int world_hit(const TraceParams &P, F &f, uint32_t *wave_masks, bool active, V3 o, V3 d, Hit &hit, float &t_out,
+                     Prof<PROF> &prof) {
+    float tbest = kMaxFloat;
+    int slot = closest_sphere(P, f, wave_masks, active, o, d, tbest, prof);
+    int obj = -1;
+    if (slot >= 0) {
+        obj = P.sph_obj[slot];
+        f4v s = f.load1(slot);  // (center, radius)
+        hit.point = o + tbest * d;                                         // Lib.metal:241
+        V3 outward = (hit.point - v3(s.x, s.y, s.z)) / s.w;                // Lib.metal:242
+        apply_normals(hit, d, outward);
+    }
+    for (int q = 0; active && q < P.nquad; ++q) {
+        QuadDev quad = P.quads[q];
+        float t;
+        V3 point, normal;
+        if (hit_quad(quad, o, d, tbest, t, point, normal)) {
+            // world_hit keeps a later object only when strictly closer (Shaders.metal:21); objects are
+            // visited here out of index order, so an equal distance goes to the lower index.
+            if (t < tbest || (t == tbest && obj >= 0 && quad.obj < obj)) {
+                tbest = t;
+                obj = quad.obj;
+                hit.point = point;
+                apply_normals(hit, d, normal);
+            }
+        }
+    }
+    t_out = tbest;
+    prof.lap(3);
+    return obj;
+}
+
+// The parameter block as it lies in the kernel argument segment, behind a pointer the optimiser cannot see
+// through: loads of the cold fields stay where they are written instead of being hoisted to kernel entry and
+// held in scalar registers across the sphere loop.
+RT_DEV const TraceParams *cold_params() {
+    const TraceParams *p = (const TraceParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+// Dynamic LDS layout: [candidate words: 4 waves x kMaskWordsPerWave] then, by fetch kind,
+//   kFetchLds:    compact records, strict records, each 4 * (ngroups + 1) x 16 B, staged by the workgroup;
+//   kFetchStream: 4 waves x 2 tiles x kTileRecords x 16 B;
+//   kFetchScalar: nothing.
+template <int KIND>
+RT_DEV void stage_scene(const TraceParams &P, uint32_t *lds_words, uint32_t *&wave_masks, Fetch<KIND> &f) {
+    const int wave = threadIdx.x >> 6;
+    wave_masks = lds_words + wave * kMaskWordsPerWave;
+    uint32_t *after_masks = lds_words + (blockDim.x >> 6) * kMaskWordsPerWave;
+    if constexpr (KIND == kFetchLds) {
+        const int n = 4 * (P.ngroups + 1);
+        f4v *c = (f4v *)after_masks;
+        f4v *g = c + n;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            c[i] = ((const f4v *)P.sphc)[i];
+            g[i] = ((const f4v *)P.sphg)[i];
+        }
+        __syncthreads();
+        f.pc = c;
+        f.pg = g;
+    } else if constexpr (KIND == kFetchScalar) {
+        f.pc = (const_f4_ptr)(uintptr_t)P.sphc;
+        f.pg = (const_f4_ptr)(uintptr_t)P.sphg;
+        f.strict = (const f4v *)P.sphg;
+    } else {
+        f.gc = (const f4v *)P.sphc;
+        f.gg = (const f4v *)P.sphg;
+        f.tile = (f4v *)after_masks + wave * 2 * kTileRecords;
+        f.lane = threadIdx.x & 63;
+    }
+}
+
+}  // namespace rt

@@ -49,6 +49,10 @@ struct TraceParams {
 // fetch_kind: 0 records staged in LDS per workgroup, 1 scalar cache, 2 streamed through per-wave LDS tiles
 hipError_t launch_trace(const TraceParams &P, int fetch_kind, bool profile, int blocks, hipStream_t stream);
 int trace_blocks_per_cu(const TraceParams &P, int fetch_kind);
+// Wavefront formulation (rt_wavefront.hip): blocks until the launch is complete.
+size_t wavefront_pool_alloc_bytes(int slots);
+hipError_t run_wavefront(const TraceParams &P, int fetch_kind, void *pool, int slots, int extend_blocks, hipStream_t stream,
+                         int *steps_out);
 hipError_t launch_first_hit(const TraceParams &P, float4 *out4, int *ids, hipStream_t stream);
 hipError_t launch_filter_selftest(uint32_t seed, int blocks, int pairs_per_thread, unsigned long long *out,
                                   hipStream_t stream);

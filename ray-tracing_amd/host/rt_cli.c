@@ -20,7 +20,7 @@ static double now_s(void) {
 
 int main(int argc, char **argv) {
     const char *scene = "cover", *out = NULL;
-    int width = 1200, height = 675, spp = 100, depth = 50, passes = 0, chunk = -1, fetch = 0, stamps = 0, filter = 0, bpc = 0;
+    int width = 1200, height = 675, spp = 100, depth = 50, passes = 0, chunk = -1, fetch = 0, stamps = 0, filter = 0, bpc = 0, wavefront = 0, slots = 0;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--scene") && i + 1 < argc) scene = argv[++i];
         else if (!strcmp(argv[i], "--width") && i + 1 < argc) width = atoi(argv[++i]);
@@ -31,6 +31,8 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--chunk") && i + 1 < argc) chunk = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--fetch") && i + 1 < argc) fetch = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--stamps")) stamps = 1;
+        else if (!strcmp(argv[i], "--wavefront")) wavefront = 1;
+        else if (!strcmp(argv[i], "--slots") && i + 1 < argc) slots = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--filter") && i + 1 < argc) filter = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--blocks-per-cu") && i + 1 < argc) bpc = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
@@ -60,6 +62,8 @@ int main(int argc, char **argv) {
     if (chunk >= 0) rt_set_option(ctx, RT_OPT_CHUNK, chunk);
     rt_set_option(ctx, RT_OPT_SCENE_FETCH, fetch);
     if (stamps) rt_set_option(ctx, RT_OPT_KERNEL, 2);
+    if (wavefront) rt_set_option(ctx, RT_OPT_KERNEL, 1);
+    if (slots) rt_set_option(ctx, RT_OPT_WAVEFRONT_SLOTS, slots);
     rt_set_option(ctx, RT_OPT_FILTER, filter);
     rt_set_option(ctx, RT_OPT_BLOCKS_PER_CU, bpc);
 

@@ -287,7 +287,8 @@ def test_sphere_filter_never_misses_a_reference_candidate(rt, renderer):
         assert r["general"] <= r["compact"] < 2 * r["reference"]
 
 
-@pytest.mark.parametrize("opt,val", [("RT_OPT_FILTER", 1), ("RT_OPT_SCENE_FETCH", 1), ("RT_OPT_SCENE_FETCH", 2)])
+@pytest.mark.parametrize("opt,val", [("RT_OPT_FILTER", 1), ("RT_OPT_SCENE_FETCH", 1), ("RT_OPT_SCENE_FETCH", 2),
+                                     ("RT_OPT_KERNEL", 1)])
 def test_kernel_variants_bit_exact(rt, oracle, renderer, opt, val):
     """General-only filter, scalar-cache fetch and streamed fetch give the same bits as the defaults."""
     strict(renderer, rt)
@@ -302,3 +303,29 @@ def test_kernel_variants_bit_exact(rt, oracle, renderer, opt, val):
     finally:
         renderer.set_option(getattr(rt, opt), 0)
     assert np.array_equal(bits(img), bits(want))
+
+
+@pytest.mark.parametrize("name,w,h,spp,depth,slots", [("cornell", 120, 96, 8, 10, 1 << 20), ("nested_glass", 96, 54, 4, 100, 2048),
+                                                       ("three_spheres", 400, 225, 20, 50, 4096)])
+def test_wavefront_kernels_bit_exact(rt, oracle, renderer, name, w, h, spp, depth, slots):
+    """generate / extend / shade kernels with compacted queues: same bits as the oracle, also when the pool is much
+    smaller than the number of work items (slots are reused) and with quads, emission and 100-bounce paths."""
+    strict(renderer, rt, chunk=3)
+    objs, n = rt.scene(name)
+    u = rt.config_uniforms(name, w, h, spp, depth, n)
+    renderer.setupTexture(w, h)
+    renderer.set_option(rt.RT_OPT_KERNEL, 1)
+    renderer.set_option(rt.RT_OPT_WAVEFRONT_SLOTS, slots)
+    try:
+        img = renderer.renderImage(u, objs, n, chunk=3)
+        st = renderer.lastStats()
+    finally:
+        renderer.set_option(rt.RT_OPT_KERNEL, 0)
+        renderer.set_option(rt.RT_OPT_WAVEFRONT_SLOTS, 1 << 20)
+    acc = np.zeros((h, w, 4), np.float32)
+    for b in range(0, spp, 3):
+        acc = acc + oracle.accumulate(u, objs, w, h, b, min(b + 3, spp))
+    assert np.array_equal(bits(img), bits(oracle.resolve(acc, spp)))
+    stats = [0] * 5
+    oracle.image(u, objs, w, h, stats=stats)
+    assert st.segments == stats[0]
