@@ -59,8 +59,12 @@ enum {
                                1 = through the scalar cache into scalar registers,
                                2 = streamed from global memory through per-wave LDS tiles */
     RT_OPT_BLOCKS_PER_CU = 5, /* persistent grid size = this x compute units; 0 = occupancy query */
-    RT_OPT_FILTER = 6,      /* 0 = compact 9-instruction sphere filter where the scene allows it (default),
-                               1 = always the translation-invariant 12-instruction filter; results are identical */
+    RT_OPT_FILTER = 6,      /* which conservative sphere filter precedes the exact hit test; results are identical:
+                               0 = automatic (default): the matrix-core filter for LDS-staged scenes of 48 to 1024
+                                   spheres that its FP16 range covers, else the compact 9-instruction vector filter,
+                               1 = always the translation-invariant 12-instruction vector filter,
+                               2 = vector filters only (compact where the scene allows it),
+                               3 = the matrix-core filter for any staged scene it covers, however small */
     RT_OPT_WAVEFRONT_SLOTS = 7 /* path slots of the wavefront pool (default 2^20; 168 bytes of device memory each) */
 };
 
@@ -136,6 +140,8 @@ struct rt_stats {
     float kernel_ms;
     int grid_blocks;
     int block_threads;
+    int scene_path;  /* how the last trace launch read and filtered the spheres: 0 staged in LDS + vector filter,
+                        1 scalar cache + vector filter, 2 streamed + vector filter, 3 staged in LDS + matrix-core filter */
     /* RT_OPT_KERNEL = 2 only, summed over waves, in shader clock cycles: [0] generate rays / draw work,
      * [1] sphere filter pass, [2] exact resolve of candidates, [3] quads + hit record, [4] shading,
      * [5] number of main-loop trips (not cycles). */
@@ -154,6 +160,14 @@ RT_API int rt_trace_times(rt_ctx *ctx, float *ms, int cap, int *count);
  * filter, out[4] / out[5] pairs with discriminant >= 0 that the general / compact filter failed to flag.
  * out[4] and out[5] must be 0: the filters may only over-report. */
 RT_API int rt_selftest_filter(rt_ctx *ctx, uint32_t seed, int blocks, int pairs_per_thread, uint64_t out[6]);
+
+/* No counterpart in the reference.  The same guarantee for the matrix-core filter: every wave of blocks x 4 draws
+ * a scene frame and, `rounds` times, 64 spheres and 64 rays aimed at their silhouettes, and checks all 64 x 64
+ * pairs.  slack_log2 = -16 is the slack the library renders with; larger negative values probe the margin.
+ * out[0] pairs checked, out[1] pairs whose reference discriminant is >= 0, out[2] pairs the filter flagged,
+ * out[3] misses (must be 0 at -16), out[4] pairs outside the filter's range (not filtered when rendering),
+ * out[5] out-of-range spheres that were not handed on as candidates (must be 0). */
+RT_API int rt_selftest_matrix_filter(rt_ctx *ctx, uint32_t seed, int blocks, int rounds, int slack_log2, uint64_t out[6]);
 
 #ifdef __cplusplus
 }

@@ -80,7 +80,8 @@ class TileInfo(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("segments", C.c_uint64), ("tests", C.c_uint64), ("samples", C.c_uint64), ("kernel_ms", C.c_float),
-                ("grid_blocks", C.c_int), ("block_threads", C.c_int), ("phase_cycles", C.c_uint64 * 6)]
+                ("grid_blocks", C.c_int), ("block_threads", C.c_int), ("scene_path", C.c_int),
+                ("phase_cycles", C.c_uint64 * 6)]
 
 
 RT_OPT_CHUNK, RT_OPT_KERNEL, RT_OPT_SCENE_FETCH, RT_OPT_BLOCKS_PER_CU, RT_OPT_FILTER, RT_OPT_WAVEFRONT_SLOTS = 1, 3, 4, 5, 6, 7
@@ -90,7 +91,7 @@ AMD_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_option", "rt_get_option", "rt_set_target", "rt_clear",
     "rt_write_target", "rt_read_target", "rt_render_tile", "rt_present_bgra8", "rt_set_scene", "rt_render",
     "rt_accum_clear", "rt_accum_ptr", "rt_resolve", "rt_synchronize", "rt_first_hit", "rt_last_stats", "rt_trace_times",
-    "rt_selftest_filter",
+    "rt_selftest_filter", "rt_selftest_matrix_filter",
 ]
 HOST_SYMBOLS = [
     "rt_material_default", "rt_material_lambertian", "rt_material_metal", "rt_material_dielectric", "rt_material_light",
@@ -132,6 +133,7 @@ def amd_lib():
         lib.rt_last_stats.argtypes = [vp, C.POINTER(Stats)]
         lib.rt_trace_times.argtypes = [vp, vp, ip, C.POINTER(ip)]
         lib.rt_selftest_filter.argtypes = [vp, C.c_uint32, ip, ip, vp]
+        lib.rt_selftest_matrix_filter.argtypes = [vp, C.c_uint32, ip, ip, ip, vp]
         _amd = lib
     return _amd
 
@@ -437,6 +439,11 @@ class MetalRenderer:
         out = (C.c_uint64 * 6)()
         self._check(self._lib.rt_selftest_filter(self._ctx, seed, blocks, pairs_per_thread, out))
         return dict(zip(["pairs", "reference", "general", "compact", "general_missed", "compact_missed"], list(out)))
+
+    def selftestMatrixFilter(self, seed=1, blocks=1024, rounds=64, slack_log2=-16):
+        out = (C.c_uint64 * 6)()
+        self._check(self._lib.rt_selftest_matrix_filter(self._ctx, seed, blocks, rounds, slack_log2, out))
+        return dict(zip(["pairs", "reference", "matrix", "missed", "out_of_range", "unflagged"], list(out)))
 
     def renderImage(self, u, objs, n, chunk=None):
         """Whole image in one go: clear accumulation, trace u.sampleCount samples, resolve, read back."""

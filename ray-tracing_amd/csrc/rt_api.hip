@@ -38,6 +38,10 @@ struct rt_ctx {
 
     // compact scene
     DevBuf<float4> sph, sphc;
+    DevBuf<_Float16> sphm;  // matrix-core filter: lifted A operands (rt_lift.hpp)
+    LiftFrame lift = {0.0f, 0.0f, 0.0f, 1.0f};
+    float oo_limit_m = -1.0f;  // origin limit of the matrix-core filter in the lifted frame; < 0: scene not eligible
+    int matrix_outliers = 0;   // spheres the matrix-core filter always passes on to the exact test
     DevBuf<int> sph_obj;
     DevBuf<QuadDev> quads;
     DevBuf<MatDev> mats;
@@ -68,6 +72,9 @@ namespace {
 // Largest sphere count the optional LDS staging accepts (two 16-byte records each): 1792 spheres = 56 KiB,
 // which with the 16 KiB of candidate words leaves room for two workgroups per compute unit in the 160 KiB LDS.
 constexpr int kMaxLdsSpheres = 1792;
+// Matrix-core filter: 80 bytes per sphere (lifted operand + strict record) next to 4 KiB of candidate words per
+// wave; 1024 spheres = 80 KiB leave room for a 1024-thread workgroup's 64 KiB of words in the 160 KiB LDS.
+constexpr int kMaxMatrixSpheres = 1024;
 
 int fail(rt_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
     if (c) {
@@ -187,6 +194,65 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n) {
         double lim = budget[k];  // 10th percentile: 90 % of the spheres keep their inflation below 25 %
         oo_limit = lim > 0.0 ? (float)std::min(lim, 1e30) : -1.0f;
     }
+    // Matrix-core filter (rt_lift.hpp): frame = median centre and a power-of-two scale that puts the 95th
+    // percentile of |c - T|_inf + r near 42 (of the 244 that the FP16 range allows for a ray origin), lifted
+    // records in A-operand order, and the origin limit: the hard range limit, or less when 10 % of the spheres
+    // would see their filter radius^2 doubled by the slack.
+    std::vector<_Float16> sphm;
+    LiftFrame frame = {0.0f, 0.0f, 0.0f, 1.0f};
+    float oo_limit_m = -1.0f;
+    int outliers = 0;
+    if (nsph > 0) {
+        std::vector<float> med[3];
+        for (int i = 0; i < nsph; ++i) {
+            med[0].push_back(sph[(size_t)i].x); med[1].push_back(sph[(size_t)i].y); med[2].push_back(sph[(size_t)i].z);
+        }
+        float t[3];
+        for (int a = 0; a < 3; ++a) {
+            std::nth_element(med[a].begin(), med[a].begin() + nsph / 2, med[a].end());
+            t[a] = med[a][(size_t)(nsph / 2)];
+            if (!std::isfinite(t[a])) t[a] = 0.0f;
+        }
+        frame.tx = t[0]; frame.ty = t[1]; frame.tz = t[2];
+        std::vector<double> ext;
+        for (int i = 0; i < nsph; ++i) {
+            const float4 &q = sph[(size_t)i];
+            double e = std::max(std::fabs((double)q.x - t[0]), std::max(std::fabs((double)q.y - t[1]), std::fabs((double)q.z - t[2]))) +
+                       std::fabs((double)q.w);
+            ext.push_back(std::isfinite(e) ? e : 0.0);
+        }
+        size_t k95 = (size_t)((double)(nsph - 1) * 0.95);
+        std::nth_element(ext.begin(), ext.begin() + (long)k95, ext.end());
+        double e95 = ext[k95];
+        int ex = (e95 > 0.0 && std::isfinite(e95)) ? (int)std::floor(std::log2(42.5 / e95)) : 0;
+        ex = std::max(-60, std::min(60, ex));
+        frame.sigma = std::ldexp(1.0f, ex);
+        const int nblocks = (nsph + 63) / 64;
+        sphm.assign((size_t)nblocks * 64 * kLiftSlots, (_Float16)0.0f);
+        std::vector<double> room;
+        for (int i = 0; i < nblocks * 64; ++i) {
+            _Float16 slots[kLiftSlots];
+            if (i < nsph) {
+                const float4 &q = sph[(size_t)i];
+                if (lift_sphere(q.x, q.y, q.z, q.w, frame, (double)kMfmaSlack, slots)) {
+                    const double g = frame.sigma;
+                    const double x = ((double)q.x - t[0]) * g, y = ((double)q.y - t[1]) * g, z = ((double)q.z - t[2]) * g, r2 = (double)q.w * g * ((double)q.w * g);
+                    room.push_back(r2 / (double)kMfmaSlack - (x * x + y * y + z * z) - r2);
+                } else {
+                    ++outliers;
+                }
+            } else {
+                lift_constant(false, slots);
+            }
+            for (int k = 0; k < kLiftSlots; ++k) sphm[lift_index(i / 64, i % 64, k)] = slots[k];
+        }
+        if (!room.empty() && outliers <= std::max(2, nsph / 16)) {
+            size_t k = room.size() / 10;
+            std::nth_element(room.begin(), room.begin() + (long)k, room.end());
+            double lim = std::min(room[k], 57000.0);
+            if (lim > 0.0) oo_limit_m = (float)lim;
+        }
+    }
     while ((int)sph.size() < nslots) {
         sph.push_back(make_float4(0.0f, 0.0f, 0.0f, std::numeric_limits<float>::quiet_NaN()));    // never a hit
         sphc.push_back(make_float4(0.0f, 0.0f, 0.0f, std::numeric_limits<float>::infinity()));    // q = -inf
@@ -194,6 +260,7 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n) {
     }
     RT_TRY(upload(ctx, ctx->sph, sph));
     RT_TRY(upload(ctx, ctx->sphc, sphc));
+    RT_TRY(upload(ctx, ctx->sphm, sphm));
     RT_TRY(upload(ctx, ctx->sph_obj, sph_obj));
     RT_TRY(upload(ctx, ctx->quads, quads));
     RT_TRY(upload(ctx, ctx->mats, mats));
@@ -202,6 +269,9 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n) {
     ctx->nsph = nsph;
     ctx->ngroups = ngroups;
     ctx->oo_limit = oo_limit;
+    ctx->lift = frame;
+    ctx->oo_limit_m = oo_limit_m;
+    ctx->matrix_outliers = outliers;
     ctx->nquad = (int)quads.size();
     ctx->nobj = n;
     return RT_OK;
@@ -240,6 +310,8 @@ void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
     P.nsph = ctx->nsph;
     P.nquad = ctx->nquad;
     P.oo_limit = ctx->opt_filter == 1 ? -1.0f : ctx->oo_limit;
+    P.sphm = ctx->sphm.ptr;
+    P.lift = ctx->lift;
     P.width = ctx->width;
     P.height = ctx->height;
     P.pass = u->currentSample;
@@ -254,10 +326,19 @@ void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
 int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
     // 0: staged in LDS when the scene fits, else scalar cache (measured faster than streaming on a 100 000-sphere
     // scene: 84 vs 78 TFLOP/s algorithmic); 1: scalar cache; 2: streamed through per-wave LDS tiles
-    const int kind = ctx->opt_fetch == 2 ? 2 : (ctx->opt_fetch == 0 && 4 * P.ngroups <= kMaxLdsSpheres) ? 0 : 1;
-    int per_cu = ctx->opt_blocks_per_cu > 0 ? ctx->opt_blocks_per_cu : trace_blocks_per_cu(P, kind);
+    int kind = ctx->opt_fetch == 2 ? 2 : (ctx->opt_fetch == 0 && 4 * P.ngroups <= kMaxLdsSpheres) ? 0 : 1;
+    // Matrix-core filter: staged scenes the lifted form covers (rt_lift.hpp), from 48 spheres up -- below that the
+    // fixed cost of lifting the ray outweighs the vector filter -- or any size when asked for with RT_OPT_FILTER 3.
+    if (kind == 0 && ctx->opt_kernel != 1 && ctx->oo_limit_m > 0.0f && 4 * P.ngroups <= kMaxMatrixSpheres &&
+        ((ctx->opt_filter == 0 && ctx->nsph >= 48) || ctx->opt_filter == 3)) {
+        kind = 3;
+        P.oo_limit = ctx->oo_limit_m;
+    }
+    int threads = 256, per_cu = 1;
+    trace_launch_shape(P, kind, &threads, &per_cu);
+    if (ctx->opt_blocks_per_cu > 0) per_cu = ctx->opt_blocks_per_cu;
     long long blocks = (long long)per_cu * ctx->num_cus;
-    long long need = ((long long)P.nitems + 255) / 256;
+    long long need = ((long long)P.nitems + threads - 1) / threads;
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
     RT_HIP(hipMemsetAsync(ctx->counters, 0, 256, ctx->stream));
@@ -276,14 +357,15 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
         blocks = slots / 256;
     } else {
         RT_HIP(hipEventRecord(ctx->ev0[slot], ctx->stream));
-        RT_HIP(launch_trace(P, kind, ctx->opt_kernel == 2, (int)blocks, ctx->stream));
+        RT_HIP(launch_trace(P, kind, ctx->opt_kernel == 2, (int)blocks, threads, ctx->stream));
         RT_HIP(hipEventRecord(ctx->ev1[slot], ctx->stream));
     }
     ctx->launches++;
     ctx->stats_pending = true;
     ctx->last = {};
     ctx->last.grid_blocks = (int)blocks;
-    ctx->last.block_threads = 256;
+    ctx->last.block_threads = ctx->opt_kernel == 1 ? 256 : threads;
+    ctx->last.scene_path = kind;
     return RT_OK;
 }
 
@@ -338,6 +420,7 @@ RT_API void rt_destroy(rt_ctx *ctx) {
     (void)hipFree(ctx->wf_pool.ptr);
     (void)hipFree(ctx->sph.ptr);
     (void)hipFree(ctx->sphc.ptr);
+    (void)hipFree(ctx->sphm.ptr);
     (void)hipFree(ctx->sph_obj.ptr);
     (void)hipFree(ctx->quads.ptr);
     (void)hipFree(ctx->mats.ptr);
@@ -372,7 +455,7 @@ RT_API int rt_set_option(rt_ctx *ctx, int key, int value) {
             ctx->opt_blocks_per_cu = value;
             return RT_OK;
         case RT_OPT_FILTER:
-            if (value != 0 && value != 1) return fail(ctx, RT_ERR_INVALID, "rt: filter must be 0 or 1");
+            if (value < 0 || value > 3) return fail(ctx, RT_ERR_INVALID, "rt: filter must be 0, 1, 2 or 3");
             ctx->opt_filter = value;
             return RT_OK;
         case RT_OPT_WAVEFRONT_SLOTS:
@@ -633,6 +716,22 @@ RT_API int rt_selftest_filter(rt_ctx *ctx, uint32_t seed, int blocks, int pairs_
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(dev);
     if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_selftest_filter", e);
+    for (int i = 0; i < 6; ++i) out[i] = host[i];
+    return RT_OK;
+}
+
+RT_API int rt_selftest_matrix_filter(rt_ctx *ctx, uint32_t seed, int blocks, int rounds, int slack_log2, uint64_t out[6]) {
+    if (!ctx || !out || blocks <= 0 || rounds <= 0 || slack_log2 > -8 || slack_log2 < -30) return RT_ERR_INVALID;
+    Bind bind(ctx);
+    unsigned long long *dev = nullptr;
+    RT_HIP(hipMalloc((void **)&dev, 256));
+    hipError_t e = hipMemsetAsync(dev, 0, 256, ctx->stream);
+    if (e == hipSuccess) e = launch_matrix_selftest(seed, blocks, rounds, std::ldexp(1.0f, slack_log2), dev, ctx->stream);
+    unsigned long long host[6] = {0, 0, 0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(host, dev, sizeof host, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_selftest_matrix_filter", e);
     for (int i = 0; i < 6; ++i) out[i] = host[i];
     return RT_OK;
 }

@@ -9,6 +9,7 @@
 
 #include "rt_device.hpp"
 #include "rt_kernels.h"
+#include "rt_lift.hpp"
 
 namespace rt {
 
@@ -30,14 +31,20 @@ struct Rec4 { f4v r0, r1, r2, r3; };
 // Where pass A reads its records from.  All three kinds expose: start(general) -- choose the record array for
 // this closest-hit search; begin_word(group) -- called before each 32-sphere word; load4(group) / settle();
 // load1(slot) -- the strict record (center, radius) of one sphere for pass B and the hit record.
-enum { kFetchLds = 0, kFetchScalar = 1, kFetchStream = 2 };
+// kFetchMatrix is the staged kind with the matrix-core filter in place of the compact vector filter: strict
+// records and the lifted A operands (rt_lift.hpp) are staged in LDS.
+enum { kFetchLds = 0, kFetchScalar = 1, kFetchStream = 2, kFetchMatrix = 3 };
 constexpr int kTileRecords = 128;  // kFetchStream: records per LDS tile (two tiles per wave)
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int KIND>
 struct Fetch;
 
 template <>
 struct Fetch<kFetchLds> {  // both arrays staged once per workgroup in LDS, read with a wave-uniform address (broadcast)
+    static constexpr bool kMatrix = false;
     const f4v *pc, *pg, *p;
     RT_DEV void start(bool general) { p = general ? pg : pc; }
     RT_DEV void begin_word(int) {}
@@ -52,6 +59,7 @@ struct Fetch<kFetchLds> {  // both arrays staged once per workgroup in LDS, read
 
 template <>
 struct Fetch<kFetchScalar> {  // scalar cache: uniform address -> s_load_dwordx16 into scalar registers
+    static constexpr bool kMatrix = false;
     const_f4_ptr pc, pg, p;
     const f4v *strict;
     RT_DEV void start(bool general) { p = general ? pg : pc; }
@@ -78,6 +86,7 @@ struct Fetch<kFetchScalar> {  // scalar cache: uniform address -> s_load_dwordx1
 // wrote itself, and LDS operations of one wave execute in order.
 template <>
 struct Fetch<kFetchStream> {
+    static constexpr bool kMatrix = false;
     const f4v *gc, *gg, *src;
     f4v *tile;  // this wave's 2 x kTileRecords records
     f4v pre0, pre1;
@@ -109,6 +118,22 @@ struct Fetch<kFetchStream> {
     }
     RT_DEV void settle(Rec4 &) const {}
     RT_DEV f4v load1(int k) const { return gg[k]; }
+};
+
+template <>
+struct Fetch<kFetchMatrix> {  // strict records and lifted A operands staged in LDS; the vector path is the general filter
+    static constexpr bool kMatrix = true;
+    const f4v *pg;
+    const h8 *pm;  // [32-sphere group][K half][lane]
+    RT_DEV void start(bool) {}
+    RT_DEV void begin_word(int) {}
+    RT_DEV Rec4 load4(int group) const {
+        const f4v *q = pg + 4 * group;
+        Rec4 r = {q[0], q[1], q[2], q[3]};
+        return r;
+    }
+    RT_DEV void settle(Rec4 &) const {}
+    RT_DEV f4v load1(int k) const { return pg[k]; }
 };
 
 // Optional in-kernel cycle stamps (diagnostic instantiation only): wave-level s_memtime differences summed
@@ -201,6 +226,108 @@ RT_DEV uint32_t filter_round(F &f, int g0, int g1, int nsph, uint32_t *masks, in
     return nz;
 }
 
+// ---- matrix-core filter (rt_lift.hpp) -----------------------------------------------------------------------
+// B operands of the wave's 64 rays: [ray half][K half], lane l supplying column l % 32, K slots 8 (l / 32) .. + 7.
+struct RayLifted { h8 b00, b01, b10, b11; };
+
+// v0 keeps its lanes 0-31 and receives v1's lanes 0-31 in its lanes 32-63; v1 the other way round.
+RT_DEV void swap_halves(uint32_t &v0, uint32_t &v1) {
+    auto r = __builtin_amdgcn_permlane32_swap(v0, v1, false, false);
+    v0 = r[0];
+    v1 = r[1];
+}
+RT_DEV void swap_halves(h8 &x0, h8 &x1) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 a = __builtin_bit_cast(u4, x0), b = __builtin_bit_cast(u4, x1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t p = a[i], q = b[i];
+        swap_halves(p, q);
+        a[i] = p;
+        b[i] = q;
+    }
+    x0 = __builtin_bit_cast(h8, a);
+    x1 = __builtin_bit_cast(h8, b);
+}
+
+// Ray side of the lifted form, every lane for its own ray, then the exchange that turns the per-lane slot vectors
+// into the four B operands.  oo is |o'|^2 in the scaled frame (the caller compares it with the scene's limit).
+RT_DEV void lift_ray(const LiftFrame &F, V3 o, V3 dn, float slack, float &oo, RayLifted &L) {
+    const float ox = (o.x - F.tx) * F.sigma, oy = (o.y - F.ty) * F.sigma, oz = (o.z - F.tz) * F.sigma;
+    oo = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
+    const float odn = __builtin_fmaf(oz, dn.z, __builtin_fmaf(oy, dn.y, ox * dn.x));
+    float v[10];
+    v[0] = __builtin_fmaf(odn, odn, -(oo * (1.0f - slack)));
+    v[1] = 2.0f * __builtin_fmaf(-odn, dn.x, ox);
+    v[2] = 2.0f * __builtin_fmaf(-odn, dn.y, oy);
+    v[3] = 2.0f * __builtin_fmaf(-odn, dn.z, oz);
+    v[4] = dn.x * dn.x; v[5] = dn.y * dn.y; v[6] = dn.z * dn.z;
+    v[7] = dn.x * dn.y; v[8] = dn.x * dn.z; v[9] = dn.y * dn.z;
+    // The FP16 pairs must satisfy hi + lo = v to 2^-22: pin each v as a binary32 value so that both uses of its
+    // conversion round the same number (otherwise the compiler converts one of them straight from the unrounded
+    // fused product, and the two halves of the pair can then disagree by a whole FP16 ulp).
+#pragma unroll
+    for (int i = 0; i < 10; ++i) asm volatile("" : "+v"(v[i]));
+    _Float16 r[kLiftSlots];
+    _Float16 hi = (_Float16)v[0];
+    r[0] = hi;
+    r[1] = (_Float16)(v[0] - (float)hi);
+    r[2] = r[3] = r[4] = (_Float16)1.0f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        hi = (_Float16)v[1 + t];
+        r[5 + 3 * t] = hi;
+        r[6 + 3 * t] = hi;
+        r[7 + 3 * t] = (_Float16)(v[1 + t] - (float)hi);
+    }
+    h8 x00, x01, x10, x11;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { x00[i] = r[i]; x01[i] = r[8 + i]; x10[i] = r[16 + i]; x11[i] = r[24 + i]; }
+    swap_halves(x00, x01);  // -> K half 0 of ray halves 0 and 1
+    swap_halves(x10, x11);  // -> K half 1
+    L.b00 = x00; L.b10 = x01;
+    L.b01 = x10; L.b11 = x11;
+}
+
+// Pass A on the matrix cores over 64-sphere blocks [blk0, blk1): same candidate words as filter_round.
+//
+// The four matrix instructions of a 32-sphere group are issued back to back and fenced off from the vector code
+// on both sides with scheduling barriers.  Letting the compiler weave the sign extraction of one group between
+// the matrix instructions of the next gave results that changed from run to run on MI355X (ROCm 7.2 compiler;
+// caught by rt_selftest_matrix_filter), so nothing but matrix instructions is in flight between the barriers,
+// and the results are read only after the whole group has been issued.
+RT_DEV void matrix_group(const h8 a_lo, const h8 a_hi, const RayLifted &L, f32x16 &q0, f32x16 &q1) {
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    __builtin_amdgcn_sched_barrier(0);
+    q0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, L.b00, zero, 0, 0, 0);
+    q1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, L.b10, zero, 0, 0, 0);
+    q0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, L.b01, q0, 0, 0, 0);
+    q1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, L.b11, q1, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+RT_DEV uint32_t filter_round_matrix(const h8 *pm, int blk0, int blk1, uint32_t *masks, int lane, const RayLifted &L) {
+    uint32_t nz = 0;
+    const h8 *A = pm + (size_t)blk0 * 256 + lane;
+    for (int blk = blk0, w = 0; blk < blk1; ++blk, w += 2, A += 256) {
+        const h8 a0 = A[0], a1 = A[64], a2 = A[128], a3 = A[192];
+        f32x16 q0, q1;
+        uint32_t w0 = 0, w1 = 0;
+        matrix_group(a0, a1, L, q0, q1);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { w0 = push_sign(w0, q0[k]); w1 = push_sign(w1, q1[k]); }
+        matrix_group(a2, a3, L, q0, q1);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { w0 = push_sign(w0, q0[k]); w1 = push_sign(w1, q1[k]); }
+        swap_halves(w0, w1);
+        const uint32_t c0 = ~w0, c1 = ~w1;
+        masks[w * 64 + lane] = c0;
+        masks[(w + 1) * 64 + lane] = c1;
+        nz |= ((c0 != 0u ? 1u : 0u) | (c1 != 0u ? 2u : 0u)) << w;
+    }
+    return nz;
+}
+
 // Closest sphere hit of ray (o, d) over all spheres: the sphere part of world_hit (Shaders.metal:13-32) with
 // hitSphere (Lib.metal:215-246).  Returns the sphere slot or -1; t in tbest.  Must be called by all 64 lanes of the
 // wave (the streaming fetcher loads tiles cooperatively); lanes without a ray pass active = false and get -1.
@@ -226,7 +353,13 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
     const bool a_ok = !(__builtin_fabsf(a) < 1e-6f);  // Lib.metal:226-228: such a ray hits no sphere
     const float s = __builtin_amdgcn_rsqf(a) * kDirScale;
     const V3 dn = v3(d.x * s, d.y * s, d.z * s);
-    const float oo = __builtin_fmaf(o.z, o.z, __builtin_fmaf(o.y, o.y, o.x * o.x));
+    float oo;
+    RayLifted lifted;
+    if constexpr (F::kMatrix) {
+        lift_ray(P.lift, o, dn, kMfmaSlack, oo, lifted);
+    } else {
+        oo = __builtin_fmaf(o.z, o.z, __builtin_fmaf(o.y, o.y, o.x * o.x));
+    }
     const bool general = __builtin_amdgcn_ballot_w64(active && !(oo <= P.oo_limit)) != 0;  // wave-uniform
     const int lane = threadIdx.x & 63;
     int ibest = -1;
@@ -238,6 +371,8 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
         if (general) {
             RayGeneral y = {o, dn};
             nz = filter_round(f, g0, g1, P.nsph, wave_masks, lane, y);
+        } else if constexpr (F::kMatrix) {
+            nz = filter_round_matrix(f.pm, g0 / 16, (g1 + 15) / 16, wave_masks, lane, lifted);
         } else {
             RayCompact y;
             y.ndnx = -dn.x; y.ndny = -dn.y; y.ndnz = -dn.z;
@@ -323,7 +458,8 @@ RT_DEV const TraceParams *cold_params() {
 // Dynamic LDS layout: [candidate words: 4 waves x kMaskWordsPerWave] then, by fetch kind,
 //   kFetchLds:    compact records, strict records, each 4 * (ngroups + 1) x 16 B, staged by the workgroup;
 //   kFetchStream: 4 waves x 2 tiles x kTileRecords x 16 B;
-//   kFetchScalar: nothing.
+//   kFetchScalar: nothing;
+//   kFetchMatrix: lifted A operands, 4 KiB per 64-sphere block, then strict records 4 * (ngroups + 1) x 16 B.
 template <int KIND>
 RT_DEV void stage_scene(const TraceParams &P, uint32_t *lds_words, uint32_t *&wave_masks, Fetch<KIND> &f) {
     const int wave = threadIdx.x >> 6;
@@ -339,6 +475,15 @@ RT_DEV void stage_scene(const TraceParams &P, uint32_t *lds_words, uint32_t *&wa
         }
         __syncthreads();
         f.pc = c;
+        f.pg = g;
+    } else if constexpr (KIND == kFetchMatrix) {
+        const int nm = ((P.ngroups + 15) / 16) * 256, n = 4 * (P.ngroups + 1);
+        f4v *m = (f4v *)after_masks;
+        f4v *g = m + nm;
+        for (int i = threadIdx.x; i < nm; i += blockDim.x) m[i] = ((const f4v *)P.sphm)[i];
+        for (int i = threadIdx.x; i < n; i += blockDim.x) g[i] = ((const f4v *)P.sphg)[i];
+        __syncthreads();
+        f.pm = (const h8 *)m;
         f.pg = g;
     } else if constexpr (KIND == kFetchScalar) {
         f.pc = (const_f4_ptr)(uintptr_t)P.sphc;

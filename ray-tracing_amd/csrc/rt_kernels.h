@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "rt_device.hpp"
+#include "rt_lift.hpp"
 
 namespace rt {
 
@@ -26,7 +27,10 @@ struct TraceParams {
     int ngroups;            // sphere slots / 4 (slots are padded to a multiple of 4 with never-hit records)
     int nsph;               // real spheres
     int nquad;
-    float oo_limit;         // rays with |origin|^2 above this use the general filter (see rt_trace.hip)
+    float oo_limit;         // rays with |origin|^2 above this use the general filter (see rt_hit.hpp); for the
+                            // matrix-core filter the origin is measured in the lifted frame
+    const void *sphm;       // matrix-core filter: lifted A operands, 4 KiB per 64-sphere block (rt_lift.hpp)
+    LiftFrame lift;         // translation and scale of the lifted frame
     int maxDepth;           // Uniforms.maxRayDepth
     V4 sky;                 // Uniforms.globalIllumation
     // ---- cold ----
@@ -46,15 +50,20 @@ struct TraceParams {
     int spp_pass;           // kModeProgressive: Uniforms.sampleCount
 };
 
-// fetch_kind: 0 records staged in LDS per workgroup, 1 scalar cache, 2 streamed through per-wave LDS tiles
-hipError_t launch_trace(const TraceParams &P, int fetch_kind, bool profile, int blocks, hipStream_t stream);
-int trace_blocks_per_cu(const TraceParams &P, int fetch_kind);
+// fetch_kind: 0 records staged in LDS per workgroup, 1 scalar cache, 2 streamed through per-wave LDS tiles,
+// 3 staged in LDS with the matrix-core filter.  threads: workgroup size (256; kind 3 also 512 or 1024).
+hipError_t launch_trace(const TraceParams &P, int fetch_kind, bool profile, int blocks, int threads, hipStream_t stream);
+// Workgroup size and resident workgroups per compute unit that give the most resident waves.
+void trace_launch_shape(const TraceParams &P, int fetch_kind, int *threads, int *blocks_per_cu);
+size_t trace_lds_bytes(const TraceParams &P, int fetch_kind, int threads);
 // Wavefront formulation (rt_wavefront.hip): blocks until the launch is complete.
 size_t wavefront_pool_alloc_bytes(int slots);
 hipError_t run_wavefront(const TraceParams &P, int fetch_kind, void *pool, int slots, int extend_blocks, hipStream_t stream,
                          int *steps_out);
 hipError_t launch_first_hit(const TraceParams &P, float4 *out4, int *ids, hipStream_t stream);
 hipError_t launch_filter_selftest(uint32_t seed, int blocks, int pairs_per_thread, unsigned long long *out,
+                                  hipStream_t stream);
+hipError_t launch_matrix_selftest(uint32_t seed, int blocks, int rounds, float slack, unsigned long long *out,
                                   hipStream_t stream);
 hipError_t launch_fold(float4 *accum, const float4 *planes, int nplanes, int width, int height, int tileX, int tileY,
                        int tileW, int tileH, hipStream_t stream);

@@ -24,7 +24,7 @@
 namespace rt {
 
 template <int KIND, bool PROF>
-__global__ __launch_bounds__(256) void trace_kernel(const TraceParams P) {
+__global__ __launch_bounds__(KIND == kFetchMatrix ? 1024 : 256) void trace_kernel(const TraceParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_words[];
     uint32_t *wave_masks;
     Fetch<KIND> fetch;
@@ -255,7 +255,125 @@ __global__ __launch_bounds__(256) void filter_selftest_kernel(uint32_t seed0, in
     if (miss_cmp) atomicAdd(&out[5], miss_cmp);
 }
 
+// Self-test of the matrix-core filter's guarantee.  Every wave draws a scene frame (scale, translation) and, per
+// round, 64 spheres and 64 rays, ray l aimed at the silhouette of sphere l; it lifts them exactly as the host and
+// closest_sphere do, runs filter_round_matrix on the block, and checks all 64 x 64 pairs against the reference's
+// discriminant.  out: [0] pairs checked (sphere and ray both inside the filter's range), [1] reference candidates,
+// [2] matrix-filter candidates, [3] misses (must be 0), [4] pairs skipped because the sphere or the ray origin is
+// outside the range (such spheres are always candidates, such rays use the vector filter), [5] out-of-range
+// spheres that an in-range ray did not get as a candidate (must be 0).
+__global__ __launch_bounds__(256) void matrix_selftest_kernel(uint32_t seed0, int rounds, float slack,
+                                                              unsigned long long *out) {
+    __shared__ __attribute__((aligned(16))) _Float16 lds_a[4][64 * kLiftSlots];
+    __shared__ uint32_t lds_masks[4][2 * 64];
+    __shared__ float4 lds_sph[4][64];
+    __shared__ int lds_ok[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t st = pcg_hash(seed0 ^ pcg_hash(blockIdx.x * 256u + threadIdx.x));
+    auto rnd = [&]() -> float { st = pcg_hash(st); return (float)(st >> 8) * (1.0f / 16777216.0f); };  // [0,1)
+    auto sym = [&]() -> float { return 2.0f * rnd() - 1.0f; };
+    // wave-uniform frame: drawn by lane 0
+    float S = __builtin_ldexpf(1.0f, (int)(rnd() * 24.0f) - 12);  // scene scale 2^-12 .. 2^11
+    V3 T = v3(S * 64.0f * sym(), S * 64.0f * sym(), S * 64.0f * sym());
+    if (rnd() < 0.3f) T = v3(0.0f, 0.0f, 0.0f);
+    S = __shfl(S, 0, 64);
+    T.x = __shfl(T.x, 0, 64); T.y = __shfl(T.y, 0, 64); T.z = __shfl(T.z, 0, 64);
+    LiftFrame F;
+    F.tx = T.x; F.ty = T.y; F.tz = T.z;
+    F.sigma = __builtin_ldexpf(1.0f, (int)__builtin_floorf(__builtin_log2f(42.5f / (16.0f * S))));
+    unsigned long long n_pairs = 0, n_ref = 0, n_mat = 0, n_miss = 0, n_skip = 0, n_unflagged = 0;
+    for (int it = 0; it < rounds; ++it) {
+        // sphere `lane`: centre within 16 S of T (a few far outside), radius S * 2^-9 .. 2 S
+        const float ext = (rnd() < 0.05f) ? 400.0f : 16.0f;
+        const V3 c = T + v3(S * ext * sym(), S * ext * sym(), S * ext * sym());
+        const float r = S * __builtin_ldexpf(1.0f + rnd(), -(int)(rnd() * 10.0f));
+        // ray `lane`: from distance r/8 .. 2048 r towards a point near the silhouette of the sphere
+        V3 u = v3(sym(), sym(), sym());
+        float ul = length(u);
+        u = ul > 1e-3f ? u / ul : v3(1.0f, 0.0f, 0.0f);
+        const float D = r * __builtin_ldexpf(1.0f + rnd(), (int)(rnd() * 14.0f) - 3);
+        const V3 o = c + D * u;
+        V3 w = v3(sym(), sym(), sym());
+        V3 v = cross(u, w);
+        float vl = length(v);
+        v = vl > 1e-3f ? v / vl : v3(0.0f, 0.0f, 0.0f);
+        const int ek = (int)(rnd() * 8.0f);
+        const float eps = (ek == 0 ? 0.0f : __builtin_ldexpf(1.0f, -24 + 3 * ek)) * (rnd() < 0.5f ? -1.0f : 1.0f);
+        const float along = (rnd() < 0.25f) ? 0.0f : sym() * r;
+        const V3 target = c + (r * (1.0f + eps)) * v + along * u;
+        V3 d = target - o;
+        d = __builtin_ldexpf(1.0f + rnd(), (int)(rnd() * 12.0f) - 6) * d;
+        if (rnd() < 0.3f) d = normalize(d);
+        const float a = dot(d, d);
+        const bool ray_ok = !(__builtin_fabsf(a) < 1e-6f) && a < 1e30f;
+
+        _Float16 slots[kLiftSlots];
+        const bool sph_ok = lift_sphere(c.x, c.y, c.z, r, F, (double)slack, slots);
+        for (int k = 0; k < kLiftSlots; ++k) lds_a[wave][lift_index(0, lane, k)] = slots[k];
+        lds_sph[wave][lane] = make_float4(c.x, c.y, c.z, r);
+        lds_ok[wave][lane] = sph_ok ? 1 : 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        const float s = __builtin_amdgcn_rsqf(a) * kDirScale;
+        const V3 dn = v3(d.x * s, d.y * s, d.z * s);
+        float oo;
+        RayLifted L;
+        lift_ray(F, o, dn, slack, oo, L);
+        const bool origin_ok = oo <= 57000.0f;
+        filter_round_matrix((const h8 *)lds_a[wave], 0, 1, lds_masks[wave], lane, L);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int j = 0; j < 64; ++j) {
+            const float4 sp = lds_sph[wave][j];
+            const bool cand = (lds_masks[wave][(j >> 5) * 64 + lane] >> (31 - (j & 31))) & 1u;
+            // the reference's discriminant (Lib.metal:216-221)
+            const float ocx = o.x - sp.x, ocy = o.y - sp.y, ocz = o.z - sp.z;
+            const float b = ocx * d.x + ocy * d.y + ocz * d.z;
+            const float cc = (ocx * ocx + ocy * ocy + ocz * ocz) - sp.w * sp.w;
+            const float disc = b * b - a * cc;
+            const bool ref = !(disc < 0.0f) && !__builtin_isnan(disc);
+            if (!ray_ok) continue;
+            if (!origin_ok) {
+                ++n_skip;
+                continue;
+            }
+            if (!lds_ok[wave][j]) {
+                ++n_skip;
+                if (!cand) ++n_unflagged;  // an out-of-range sphere must always be a candidate
+                continue;
+            }
+            ++n_pairs;
+            n_ref += ref;
+            n_mat += cand;
+            n_miss += (ref && !cand);
+#ifdef RT_SELFTEST_DEBUG
+            if (ref && !cand)
+                printf("MISS it %d lane %d j %d S %g T %g %g %g sigma %g | c %.9g %.9g %.9g r %.9g | o %.9g %.9g %.9g d %.9g %.9g %.9g | a %g disc %g oo %g\n",
+                       it, lane, j, S, T.x, T.y, T.z, F.sigma, sp.x, sp.y, sp.z, sp.w, o.x, o.y, o.z, d.x, d.y, d.z, a, disc, oo);
+#endif
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    atomicAdd(&out[0], n_pairs);
+    atomicAdd(&out[1], n_ref);
+    atomicAdd(&out[2], n_mat);
+    if (n_miss) atomicAdd(&out[3], n_miss);
+    atomicAdd(&out[4], n_skip);
+    if (n_unflagged) atomicAdd(&out[5], n_unflagged);
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------------
+
+hipError_t launch_matrix_selftest(uint32_t seed, int blocks, int rounds, float slack, unsigned long long *out,
+                                  hipStream_t stream) {
+    hipLaunchKernelGGL(matrix_selftest_kernel, dim3(blocks), dim3(256), 0, stream, seed, rounds, slack, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_filter_selftest(uint32_t seed, int blocks, int pairs_per_thread, unsigned long long *out,
                                   hipStream_t stream) {
@@ -263,47 +381,72 @@ hipError_t launch_filter_selftest(uint32_t seed, int blocks, int pairs_per_threa
     return hipGetLastError();
 }
 
-static size_t trace_lds_bytes(const TraceParams &P, int kind) {
-    size_t bytes = (size_t)4 * kMaskWordsPerWave * sizeof(uint32_t);
+size_t trace_lds_bytes(const TraceParams &P, int kind, int threads) {
+    size_t bytes = (size_t)(threads / 64) * kMaskWordsPerWave * sizeof(uint32_t);
     if (kind == kFetchLds) bytes += (size_t)8 * (P.ngroups + 1) * sizeof(f4v);
-    if (kind == kFetchStream) bytes += (size_t)4 * 2 * kTileRecords * sizeof(f4v);
+    if (kind == kFetchStream) bytes += (size_t)(threads / 64) * 2 * kTileRecords * sizeof(f4v);
+    if (kind == kFetchMatrix) bytes += (size_t)((P.ngroups + 15) / 16) * 4096 + (size_t)4 * (P.ngroups + 1) * sizeof(f4v);
     return bytes;
 }
 
 template <int KIND>
-static hipError_t launch_trace_k(const TraceParams &P, bool profile, int blocks, hipStream_t stream) {
-    size_t lds = trace_lds_bytes(P, KIND);
+static hipError_t launch_trace_k(const TraceParams &P, bool profile, int blocks, int threads, hipStream_t stream) {
+    size_t lds = trace_lds_bytes(P, KIND, threads);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(profile ? (const void *)trace_kernel<KIND, true> : (const void *)trace_kernel<KIND, false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     if (profile)
-        hipLaunchKernelGGL((trace_kernel<KIND, true>), dim3(blocks), dim3(256), lds, stream, P);
+        hipLaunchKernelGGL((trace_kernel<KIND, true>), dim3(blocks), dim3(threads), lds, stream, P);
     else
-        hipLaunchKernelGGL((trace_kernel<KIND, false>), dim3(blocks), dim3(256), lds, stream, P);
+        hipLaunchKernelGGL((trace_kernel<KIND, false>), dim3(blocks), dim3(threads), lds, stream, P);
     return hipGetLastError();
 }
 
-hipError_t launch_trace(const TraceParams &P, int fetch_kind, bool profile, int blocks, hipStream_t stream) {
+hipError_t launch_trace(const TraceParams &P, int fetch_kind, bool profile, int blocks, int threads, hipStream_t stream) {
+    if (threads != 256 && !(fetch_kind == kFetchMatrix && (threads == 512 || threads == 1024))) return hipErrorInvalidValue;
     switch (fetch_kind) {
-        case kFetchLds: return launch_trace_k<kFetchLds>(P, profile, blocks, stream);
-        case kFetchScalar: return launch_trace_k<kFetchScalar>(P, profile, blocks, stream);
-        default: return launch_trace_k<kFetchStream>(P, profile, blocks, stream);
+        case kFetchLds: return launch_trace_k<kFetchLds>(P, profile, blocks, threads, stream);
+        case kFetchScalar: return launch_trace_k<kFetchScalar>(P, profile, blocks, threads, stream);
+        case kFetchMatrix: return launch_trace_k<kFetchMatrix>(P, profile, blocks, threads, stream);
+        default: return launch_trace_k<kFetchStream>(P, profile, blocks, threads, stream);
     }
 }
 
-int trace_blocks_per_cu(const TraceParams &P, int fetch_kind) {
+static int resident_blocks(const TraceParams &P, int fetch_kind, int threads) {
     int n = 0;
-    size_t lds = trace_lds_bytes(P, fetch_kind);
+    size_t lds = trace_lds_bytes(P, fetch_kind, threads);
     hipError_t e;
     switch (fetch_kind) {
-        case kFetchLds: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<kFetchLds, false>, 256, lds); break;
-        case kFetchScalar: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<kFetchScalar, false>, 256, lds); break;
-        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<kFetchStream, false>, 256, lds); break;
+        case kFetchLds: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<kFetchLds, false>, threads, lds); break;
+        case kFetchScalar: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<kFetchScalar, false>, threads, lds); break;
+        case kFetchMatrix: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<kFetchMatrix, false>, threads, lds); break;
+        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<kFetchStream, false>, threads, lds); break;
     }
-    if (e != hipSuccess || n < 1) n = 1;
+    if (e != hipSuccess || n < 0) n = 0;
     return n;
+}
+
+void trace_launch_shape(const TraceParams &P, int fetch_kind, int *threads, int *blocks_per_cu) {
+    int best_t = 256, best_n = resident_blocks(P, fetch_kind, 256);
+    if (fetch_kind == kFetchMatrix) {
+        // one staged copy of the scene per workgroup: larger workgroups keep more waves resident when the copy is big
+        for (int t = 512; t <= 1024; t *= 2) {
+            int n = resident_blocks(P, fetch_kind, t);
+            if (n * t > best_n * best_t) {
+                best_n = n;
+                best_t = t;
+            }
+        }
+    }
+    *threads = best_t;
+    *blocks_per_cu = best_n < 1 ? 1 : best_n;
 }
 
 hipError_t launch_first_hit(const TraceParams &P, float4 *out4, int *ids, hipStream_t stream) {
     int n = P.width * P.height;
-    hipLaunchKernelGGL(first_hit_kernel, dim3((n + 255) / 256), dim3(256), trace_lds_bytes(P, kFetchScalar), stream, P, out4, ids);
+    hipLaunchKernelGGL(first_hit_kernel, dim3((n + 255) / 256), dim3(256), trace_lds_bytes(P, kFetchScalar, 256), stream, P, out4, ids);
     return hipGetLastError();
 }
 

@@ -287,10 +287,60 @@ def test_sphere_filter_never_misses_a_reference_candidate(rt, renderer):
         assert r["general"] <= r["compact"] < 2 * r["reference"]
 
 
-@pytest.mark.parametrize("opt,val", [("RT_OPT_FILTER", 1), ("RT_OPT_SCENE_FETCH", 1), ("RT_OPT_SCENE_FETCH", 2),
-                                     ("RT_OPT_KERNEL", 1)])
+def test_matrix_filter_never_misses_a_reference_candidate(rt, renderer):
+    """The same guarantee for the matrix-core filter: scene frames over 24 octaves of scale with and without a
+    translation, 64 x 64 ray/sphere pairs per round with the diagonal pairs grazing.  No miss at the slack the
+    library renders with (2^-16), nor at a sixteenth of it."""
+    for seed, slack in ((1, -16), (2, -16), (3, -20)):
+        r = renderer.selftestMatrixFilter(seed=seed, blocks=1024, rounds=48, slack_log2=slack)
+        assert r["pairs"] > 1024 * 4 * 48 * 64 * 64 // 4     # most pairs are inside the filter's range
+        assert r["reference"] > r["pairs"] // 200            # the generator really produces hits
+        assert r["missed"] == 0, r
+        assert r["reference"] <= r["matrix"] < 2 * r["reference"]
+
+
+@pytest.mark.parametrize("name,kw,w,h,spp,depth,shift", [
+    ("three_spheres", {}, 160, 90, 8, 50, 0.0),                       # one block, ground sphere outside the FP16 range
+    ("nested_glass", {}, 96, 54, 4, 100, 0.0),                        # concentric shells, 100-bounce paths
+    ("random_spheres", dict(n=700, extent=20.0), 96, 54, 4, 50, 0.0),  # 11 blocks, two filter rounds
+    ("random_spheres", dict(n=300, extent=20.0), 96, 54, 4, 50, 1000.0)])  # far from the origin: the frame translation
+def test_matrix_filter_scenes_bit_exact(rt, oracle, renderer, name, kw, w, h, spp, depth, shift):
+    """RT_OPT_FILTER = 3 puts every staged scene the lifted form covers on the matrix cores."""
+    strict(renderer, rt)
+    objs, n = rt.scene(name, **kw)
+    u = rt.config_uniforms(name, w, h, spp, depth, n)
+    if shift:
+        for i in range(n):
+            objs[i].s.center.x += shift
+            objs[i].s.center.z -= shift
+        for v in (u.cameraCenter, u.pixelOrigin):
+            v.x += shift
+            v.z -= shift
+    renderer.setupTexture(w, h)
+    renderer.set_option(rt.RT_OPT_FILTER, 3)
+    try:
+        img = renderer.renderImage(u, objs, n)
+        st = renderer.lastStats()
+    finally:
+        renderer.set_option(rt.RT_OPT_FILTER, 0)
+    assert st.scene_path == 3
+    assert np.array_equal(bits(img), bits(oracle.image(u, objs, w, h)))
+
+
+def test_default_path_of_the_cover_scene_is_the_matrix_filter(rt, renderer):
+    strict(renderer, rt)
+    objs, n = rt.scene("cover")
+    u = rt.config_uniforms("cover", 64, 36, 2, 50, n)
+    renderer.setupTexture(64, 36)
+    renderer.renderImage(u, objs, n)
+    assert renderer.lastStats().scene_path == 3
+
+
+@pytest.mark.parametrize("opt,val", [("RT_OPT_FILTER", 1), ("RT_OPT_FILTER", 2), ("RT_OPT_SCENE_FETCH", 1),
+                                     ("RT_OPT_SCENE_FETCH", 2), ("RT_OPT_KERNEL", 1)])
 def test_kernel_variants_bit_exact(rt, oracle, renderer, opt, val):
-    """General-only filter, scalar-cache fetch and streamed fetch give the same bits as the defaults."""
+    """General-only filter, vector-only filters, scalar-cache fetch and streamed fetch give the same bits as the
+    defaults."""
     strict(renderer, rt)
     w, h, spp = 240, 135, 16
     objs, n = rt.scene("cover")

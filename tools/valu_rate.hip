@@ -8,7 +8,7 @@
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 #define CHAINS 8
-#define ITERS 4096
+#define ITERS 65536
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k(float *out, float seed) {
