@@ -144,8 +144,9 @@ struct rt_stats {
                         1 scalar cache + vector filter, 2 streamed + vector filter, 3 staged in LDS + matrix-core filter */
     /* RT_OPT_KERNEL = 2 only, summed over waves, in shader clock cycles: [0] generate rays / draw work,
      * [1] sphere filter pass, [2] exact resolve of candidates, [3] quads + hit record, [4] shading,
-     * [5] number of main-loop trips (not cycles). */
-    uint64_t phase_cycles[6];
+     * [5] number of main-loop trips, [6] trips of the resolve loop, [7] candidates resolved, summed over lanes
+     * (the last three are counts, not cycles). */
+    uint64_t phase_cycles[8];
 };
 RT_API int rt_last_stats(rt_ctx *ctx, struct rt_stats *out);
 

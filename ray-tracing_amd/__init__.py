@@ -81,7 +81,7 @@ class TileInfo(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("segments", C.c_uint64), ("tests", C.c_uint64), ("samples", C.c_uint64), ("kernel_ms", C.c_float),
                 ("grid_blocks", C.c_int), ("block_threads", C.c_int), ("scene_path", C.c_int),
-                ("phase_cycles", C.c_uint64 * 6)]
+                ("phase_cycles", C.c_uint64 * 8)]
 
 
 RT_OPT_CHUNK, RT_OPT_KERNEL, RT_OPT_SCENE_FETCH, RT_OPT_BLOCKS_PER_CU, RT_OPT_FILTER, RT_OPT_WAVEFRONT_SLOTS = 1, 3, 4, 5, 6, 7

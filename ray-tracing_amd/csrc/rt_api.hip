@@ -690,14 +690,14 @@ RT_API int rt_last_stats(rt_ctx *ctx, rt_stats *out) {
         float ms = 0.0f;
         const int slot = (int)((ctx->launches - 1) % rt_ctx::kRing);
         RT_HIP(hipEventElapsedTime(&ms, ctx->ev0[slot], ctx->ev1[slot]));
-        uint32_t host[16] = {0};
+        uint32_t host[24] = {0};
         RT_HIP(hipMemcpyAsync(host, ctx->counters, sizeof host, hipMemcpyDeviceToHost, ctx->stream));
         RT_HIP(hipStreamSynchronize(ctx->stream));
         uint64_t seg = (uint64_t)host[2] | ((uint64_t)host[3] << 32);
         ctx->last.kernel_ms = ms;
         ctx->last.segments = seg;
         ctx->last.tests = seg * (uint64_t)ctx->nobj;
-        for (int i = 0; i < 6; ++i) ctx->last.phase_cycles[i] = (uint64_t)host[4 + 2 * i] | ((uint64_t)host[5 + 2 * i] << 32);
+        for (int i = 0; i < 8; ++i) ctx->last.phase_cycles[i] = (uint64_t)host[4 + 2 * i] | ((uint64_t)host[5 + 2 * i] << 32);
         ctx->stats_pending = false;
     }
     *out = ctx->last;

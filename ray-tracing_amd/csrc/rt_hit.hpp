@@ -140,7 +140,9 @@ struct Fetch<kFetchMatrix> {  // strict records and lifted A operands staged in 
 // per phase.  With PROF = false every member function is empty and nothing is emitted.
 template <bool PROF>
 struct Prof {
-    uint64_t t[6] = {0, 0, 0, 0, 0, 0};  // 0 regenerate, 1 filter pass, 2 resolve pass, 3 quads+hit record, 4 shade, 5 trips
+    // 0 regenerate, 1 filter pass, 2 resolve pass, 3 quads+hit record, 4 shade (cycles); 5 trips, 6 trips of the
+    // resolve loop, 7 candidates resolved summed over lanes (counts)
+    uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t last = 0;
     RT_DEV void start() { if constexpr (PROF) last = __builtin_amdgcn_s_memtime(); }
     RT_DEV void lap(int i) {
@@ -150,7 +152,7 @@ struct Prof {
             last = now;
         }
     }
-    RT_DEV void count(int i) { if constexpr (PROF) t[i] += 1; }
+    RT_DEV void count(int i, uint64_t n = 1) { if constexpr (PROF) t[i] += n; }
 };
 
 // Per-ray constants of the two filters.
@@ -310,13 +312,15 @@ RT_DEV uint32_t filter_round_matrix(const h8 *pm, int blk0, int blk1, uint32_t *
     uint32_t nz = 0;
     const h8 *A = pm + (size_t)blk0 * 256 + lane;
     for (int blk = blk0, w = 0; blk < blk1; ++blk, w += 2, A += 256) {
-        const h8 a0 = A[0], a1 = A[64], a2 = A[128], a3 = A[192];
         f32x16 q0, q1;
         uint32_t w0 = 0, w1 = 0;
-        matrix_group(a0, a1, L, q0, q1);
+        h8 a_lo = A[0], a_hi = A[64];
+        matrix_group(a_lo, a_hi, L, q0, q1);
+        a_lo = A[128];  // issued behind the group's barrier: the operands of one group at a time hold registers
+        a_hi = A[192];
 #pragma unroll
         for (int k = 0; k < 16; ++k) { w0 = push_sign(w0, q0[k]); w1 = push_sign(w1, q1[k]); }
-        matrix_group(a2, a3, L, q0, q1);
+        matrix_group(a_lo, a_hi, L, q0, q1);
 #pragma unroll
         for (int k = 0; k < 16; ++k) { w0 = push_sign(w0, q0[k]); w1 = push_sign(w1, q1[k]); }
         swap_halves(w0, w1);
@@ -394,6 +398,10 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
             }
             const int j = __builtin_clz(m);
             m &= ~(0x80000000u >> j);
+            if constexpr (PROF) {
+                prof.count(6);
+                prof.count(7, (uint64_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)));
+            }
             const int k = 4 * g0 + w * 32 + j;
             // Lib.metal:216-238 as written
             f4v rec = f.load1(k);  // (center, radius)

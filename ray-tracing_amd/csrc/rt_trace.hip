@@ -150,7 +150,7 @@ __global__ __launch_bounds__(KIND == kFetchMatrix ? 1024 : 256) void trace_kerne
     if ((threadIdx.x & 63) == 0 && total) atomicAdd(C->seg_counter, (unsigned long long)total);
     if constexpr (PROF) {
         if ((threadIdx.x & 63) == 0)
-            for (int i = 0; i < 6; ++i) atomicAdd(C->seg_counter + 1 + i, (unsigned long long)prof.t[i]);
+            for (int i = 0; i < 8; ++i) atomicAdd(C->seg_counter + 1 + i, (unsigned long long)prof.t[i]);
     }
 }
 

@@ -106,6 +106,9 @@ int main(int argc, char **argv) {
             for (int i = 0; i < 5; ++i)
                 printf("  %-13s %6.2f %% of wave cycles, %.0f cycles per loop trip\n", names[i], 100.0 * (double)st.phase_cycles[i] / tot,
                        (double)st.phase_cycles[i] / (double)st.phase_cycles[5]);
+            printf("  resolve loop: %.2f trips per search, %.2f candidates per lane-segment, %.1f lanes per trip\n",
+                   (double)st.phase_cycles[6] / (double)st.phase_cycles[5], (double)st.phase_cycles[7] / (double)st.segments,
+                   (double)st.phase_cycles[7] / (double)(st.phase_cycles[6] ? st.phase_cycles[6] : 1));
         }
     }
     if (out) {
