@@ -35,6 +35,7 @@ struct rt_ctx {
     int width = 0, height = 0;
     DevBuf<float4> target, accum, planes;
     DevBuf<char> wf_pool;
+    DevBuf<float4> rayq;  // camera-ray queues of the trace kernel
 
     // compact scene
     DevBuf<float4> sph, sphc;
@@ -312,6 +313,7 @@ void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
     P.oo_limit = ctx->opt_filter == 1 ? -1.0f : ctx->oo_limit;
     P.sphm = ctx->sphm.ptr;
     P.lift = ctx->lift;
+    P.nobj = ctx->nobj;
     P.width = ctx->width;
     P.height = ctx->height;
     P.pass = u->currentSample;
@@ -336,6 +338,18 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
     }
     int threads = 256, per_cu = 1;
     trace_launch_shape(P, kind, &threads, &per_cu);
+    if (kind == 3) {
+        // the slot -> object table and the materials join the staged scene when that costs no resident waves
+        P.stage_mats = 1;
+        int t2 = 256, n2 = 1;
+        trace_launch_shape(P, kind, &t2, &n2);
+        if (ctx->nobj <= 65536 && t2 * n2 >= threads * per_cu && trace_lds_bytes(P, kind, t2) <= 160 * 1024) {
+            threads = t2;
+            per_cu = n2;
+        } else {
+            P.stage_mats = 0;
+        }
+    }
     if (ctx->opt_blocks_per_cu > 0) per_cu = ctx->opt_blocks_per_cu;
     long long blocks = (long long)per_cu * ctx->num_cus;
     long long need = ((long long)P.nitems + threads - 1) / threads;
@@ -356,6 +370,8 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
         RT_HIP(hipEventRecord(ctx->ev1[slot], ctx->stream));
         blocks = slots / 256;
     } else {
+        RT_TRY(grow(ctx, ctx->rayq, (size_t)blocks * threads * kQueueRays * 2));
+        P.rayq = ctx->rayq.ptr;
         RT_HIP(hipEventRecord(ctx->ev0[slot], ctx->stream));
         RT_HIP(launch_trace(P, kind, ctx->opt_kernel == 2, (int)blocks, threads, ctx->stream));
         RT_HIP(hipEventRecord(ctx->ev1[slot], ctx->stream));
@@ -418,6 +434,7 @@ RT_API void rt_destroy(rt_ctx *ctx) {
     (void)hipFree(ctx->accum.ptr);
     (void)hipFree(ctx->planes.ptr);
     (void)hipFree(ctx->wf_pool.ptr);
+    (void)hipFree(ctx->rayq.ptr);
     (void)hipFree(ctx->sph.ptr);
     (void)hipFree(ctx->sphc.ptr);
     (void)hipFree(ctx->sphm.ptr);

@@ -55,6 +55,8 @@ struct Fetch<kFetchLds> {  // both arrays staged once per workgroup in LDS, read
     }
     RT_DEV void settle(Rec4 &) const {}
     RT_DEV f4v load1(int k) const { return pg[k]; }
+    RT_DEV int object_of(const TraceParams &P, int slot) const { return P.sph_obj[slot]; }
+    RT_DEV MatDev material(const TraceParams &P, int obj) const { return P.mats[obj]; }
 };
 
 template <>
@@ -77,6 +79,8 @@ struct Fetch<kFetchScalar> {  // scalar cache: uniform address -> s_load_dwordx1
         asm volatile("" : "+s"(r.r0), "+s"(r.r1), "+s"(r.r2), "+s"(r.r3)::"memory");
     }
     RT_DEV f4v load1(int k) const { return strict[k]; }
+    RT_DEV int object_of(const TraceParams &P, int slot) const { return P.sph_obj[slot]; }
+    RT_DEV MatDev material(const TraceParams &P, int obj) const { return P.mats[obj]; }
 };
 
 // Scenes too large for LDS: every wave streams the record array through its own pair of 128-record LDS tiles.
@@ -118,13 +122,19 @@ struct Fetch<kFetchStream> {
     }
     RT_DEV void settle(Rec4 &) const {}
     RT_DEV f4v load1(int k) const { return gg[k]; }
+    RT_DEV int object_of(const TraceParams &P, int slot) const { return P.sph_obj[slot]; }
+    RT_DEV MatDev material(const TraceParams &P, int obj) const { return P.mats[obj]; }
 };
 
 template <>
 struct Fetch<kFetchMatrix> {  // strict records and lifted A operands staged in LDS; the vector path is the general filter
     static constexpr bool kMatrix = true;
     const f4v *pg;
-    const h8 *pm;  // [32-sphere group][K half][lane]
+    const h8 *pm;        // [32-sphere group][K half][lane]
+    const uint16_t *pobj;  // staged copies of sph_obj and mats, or null when they do not fit beside the rest
+    const MatDev *pmat;
+    RT_DEV int object_of(const TraceParams &P, int slot) const { return pobj ? pobj[slot] : P.sph_obj[slot]; }
+    RT_DEV MatDev material(const TraceParams &P, int obj) const { return pmat ? pmat[obj] : P.mats[obj]; }
     RT_DEV void start(bool) {}
     RT_DEV void begin_word(int) {}
     RT_DEV Rec4 load4(int group) const {
@@ -428,7 +438,7 @@ RT_DEV int world_hit(const TraceParams &P, F &f, uint32_t *wave_masks, bool acti
     int slot = closest_sphere(P, f, wave_masks, active, o, d, tbest, prof);
     int obj = -1;
     if (slot >= 0) {
-        obj = P.sph_obj[slot];
+        obj = f.object_of(P, slot);
         f4v s = f.load1(slot);  // (center, radius)
         hit.point = o + tbest * d;                                         // Lib.metal:241
         V3 outward = (hit.point - v3(s.x, s.y, s.z)) / s.w;                // Lib.metal:242
@@ -463,11 +473,12 @@ RT_DEV const TraceParams *cold_params() {
     return p;
 }
 
-// Dynamic LDS layout: [candidate words: 4 waves x kMaskWordsPerWave] then, by fetch kind,
+// Dynamic LDS layout: [candidate words: waves x kMaskWordsPerWave] then, by fetch kind,
 //   kFetchLds:    compact records, strict records, each 4 * (ngroups + 1) x 16 B, staged by the workgroup;
 //   kFetchStream: 4 waves x 2 tiles x kTileRecords x 16 B;
 //   kFetchScalar: nothing;
-//   kFetchMatrix: lifted A operands, 4 KiB per 64-sphere block, then strict records 4 * (ngroups + 1) x 16 B.
+//   kFetchMatrix: lifted A operands, 4 KiB per 64-sphere block, then strict records 4 * (ngroups + 1) x 16 B, then
+//                 (P.stage_mats) the slot -> object table (16-bit) and the material records.
 template <int KIND>
 RT_DEV void stage_scene(const TraceParams &P, uint32_t *lds_words, uint32_t *&wave_masks, Fetch<KIND> &f) {
     const int wave = threadIdx.x >> 6;
@@ -490,9 +501,19 @@ RT_DEV void stage_scene(const TraceParams &P, uint32_t *lds_words, uint32_t *&wa
         f4v *g = m + nm;
         for (int i = threadIdx.x; i < nm; i += blockDim.x) m[i] = ((const f4v *)P.sphm)[i];
         for (int i = threadIdx.x; i < n; i += blockDim.x) g[i] = ((const f4v *)P.sphg)[i];
+        // sph_obj and the materials ride along when the launch reserved room for them (P.stage_mats)
+        uint16_t *ob = (uint16_t *)(g + n);
+        MatDev *mt = (MatDev *)(ob + 8 * ((n + 7) / 8));
+        if (P.stage_mats) {  // needs nobj <= 65536
+            for (int i = threadIdx.x; i < n; i += blockDim.x) ob[i] = (uint16_t)P.sph_obj[i];
+            const int nw = P.nobj * (int)(sizeof(MatDev) / 16);
+            for (int i = threadIdx.x; i < nw; i += blockDim.x) ((f4v *)mt)[i] = ((const f4v *)P.mats)[i];
+        }
         __syncthreads();
         f.pm = (const h8 *)m;
         f.pg = g;
+        f.pobj = P.stage_mats ? ob : nullptr;
+        f.pmat = P.stage_mats ? mt : nullptr;
     } else if constexpr (KIND == kFetchScalar) {
         f.pc = (const_f4_ptr)(uintptr_t)P.sphc;
         f.pg = (const_f4_ptr)(uintptr_t)P.sphg;

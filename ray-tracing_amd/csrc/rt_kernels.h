@@ -10,6 +10,7 @@
 namespace rt {
 
 enum { kModeAccum = 0, kModeProgressive = 1 };
+constexpr int kQueueRays = 64;  // camera rays per lane in the trace kernel's per-wave queue (two float4 each)
 
 // Everything one trace launch needs.  Passed by value in the kernel argument segment.  The first block is
 // read on every trip of the kernel's main loop and lives in scalar registers; the kernel reads the second
@@ -31,6 +32,9 @@ struct TraceParams {
                             // matrix-core filter the origin is measured in the lifted frame
     const void *sphm;       // matrix-core filter: lifted A operands, 4 KiB per 64-sphere block (rt_lift.hpp)
     LiftFrame lift;         // translation and scale of the lifted frame
+    int stage_mats;         // matrix-core kind: sph_obj and mats are staged in LDS too (the launch reserved the room)
+    int nobj;               // objects (length of mats)
+    float4 *rayq;           // per-wave queues of generated camera rays: grid lanes x kQueueRays x 2 float4
     int maxDepth;           // Uniforms.maxRayDepth
     V4 sky;                 // Uniforms.globalIllumation
     // ---- cold ----

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(KIND == kFetchMatrix ? 1024 : 256) void trace_kerne
     bool need_ray = true;   // the lane's current path is finished (or it has none yet)
     bool have_item = false;
     uint32_t px = 0, py = 0, chunk = 0;
-    int ray = 0, ray_end = 0;
+    int ray = 0, ray_end = 0, queued_end = 0;
     V4 acc = v4(0, 0, 0, 0);
     V3 o = v3(0, 0, 0), d = v3(0, 0, 0);
     V4 thr = v4(1, 1, 1, 1), fin = v4(0, 0, 0, 0);
@@ -43,14 +43,22 @@ __global__ __launch_bounds__(KIND == kFetchMatrix ? 1024 : 256) void trace_kerne
     uint32_t nseg = 0;
     Prof<PROF> prof;
     prof.start();
+    const int lane = threadIdx.x & 63;
+    // this wave's camera-ray queue (wave-uniform, held in scalar registers)
+    float4 *const queue = P.rayq + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (64 * kQueueRays * 2);
 
     for (;;) {
         prof.count(5);
         // ---- (re)generate: finish items, draw new ones, start the next camera ray ------------------
+        // Camera rays are not generated one at a time by the few lanes that happen to need one: when a lane's next
+        // sample has no ray yet, the whole wave generates that lane's next samples together -- lane j the sample
+        // with index = j (mod 64), up to the end of the item or the next multiple of 64 -- into the lane's slice of
+        // a per-wave queue in global memory, and lanes then take their rays from their own slice.
         if (__builtin_amdgcn_ballot_w64(alive && need_ray) != 0) {
             const TraceParams *C = cold_params();
-            while (alive && need_ray) {
-                if (!have_item || ray >= ray_end) {
+            for (;;) {
+                // (1) per lane: retire a finished item, draw the next one
+                if (alive && need_ray && (!have_item || ray >= ray_end)) {
                     if (have_item) {
                         size_t p = (size_t)py * C->width + px;
                         if (C->mode == kModeAccum) {
@@ -80,30 +88,66 @@ __global__ __launch_bounds__(KIND == kFetchMatrix ? 1024 : 256) void trace_kerne
                     uint32_t item = atomicAdd(C->counter, 1u);
                     if (item >= C->nitems) {
                         alive = false;
-                        break;
+                    } else {
+                        const uint32_t tile_pixels = (uint32_t)C->tileW * (uint32_t)C->tileH;
+                        chunk = item / tile_pixels;
+                        uint32_t pix = item - chunk * tile_pixels;
+                        uint32_t ty = pix / (uint32_t)C->tileW;
+                        px = (uint32_t)C->tileX + (pix - ty * (uint32_t)C->tileW);
+                        py = (uint32_t)C->tileY + ty;
+                        ray = C->ray_begin + (int)chunk * C->chunk;
+                        ray_end = min(ray + C->chunk, C->ray_end);
+                        queued_end = ray;  // nothing generated yet
+                        acc = v4(0, 0, 0, 0);
+                        have_item = true;  // an empty range comes back here on the next turn and stores zeros
                     }
-                    const uint32_t tile_pixels = (uint32_t)C->tileW * (uint32_t)C->tileH;
-                    chunk = item / tile_pixels;
-                    uint32_t pix = item - chunk * tile_pixels;
-                    uint32_t ty = pix / (uint32_t)C->tileW;
-                    px = (uint32_t)C->tileX + (pix - ty * (uint32_t)C->tileW);
-                    py = (uint32_t)C->tileY + ty;
-                    ray = C->ray_begin + (int)chunk * C->chunk;
-                    ray_end = min(ray + C->chunk, C->ray_end);
-                    acc = v4(0, 0, 0, 0);
-                    have_item = true;
-                    if (ray >= ray_end) continue;  // empty range: store zeros on the next trip
                 }
-                // Shaders.metal:121-132
-                seed = sample_seed(px, py, C->pass, ray);
-                ++ray;
-                get_ray((int)px, (int)py, C->cam, seed, d, o);
-                if (length(d) < 1e-6f || __builtin_isnan(d.x) || __builtin_isnan(d.y) || __builtin_isnan(d.z)) continue;
-                thr = v4(1, 1, 1, 1);
-                fin = v4(0, 0, 0, 0);
-                depth = 0;
-                if (P.maxDepth <= 0) continue;  // color_ray's loop body never runs: the sample is (0,0,0,0)
-                need_ray = false;
+                // (2) the wave: generate for every lane whose next sample has no ray yet
+                uint64_t fill = __builtin_amdgcn_ballot_w64(alive && need_ray && have_item && ray < ray_end && ray >= queued_end);
+                const bool filled = fill != 0;
+                while (fill) {
+                    const int L = __builtin_ctzll(fill);
+                    fill &= fill - 1;
+                    const uint32_t bx = (uint32_t)__builtin_amdgcn_readlane((int)px, L), by = (uint32_t)__builtin_amdgcn_readlane((int)py, L);
+                    const int r0 = __builtin_amdgcn_readlane(ray, L), re = __builtin_amdgcn_readlane(ray_end, L);
+                    const int lo = r0 & ~(kQueueRays - 1);
+                    const int bound = min(re, lo + kQueueRays);
+                    const int r = lo + lane;
+                    if (r >= r0 && r < bound) {
+                        // Shaders.metal:121-132
+                        Seed s2 = sample_seed(bx, by, C->pass, r);
+                        V3 gd, go;
+                        get_ray((int)bx, (int)by, C->cam, s2, gd, go);
+                        const bool bad = length(gd) < 1e-6f || __builtin_isnan(gd.x) || __builtin_isnan(gd.y) || __builtin_isnan(gd.z);
+                        float4 *slot = queue + ((size_t)L * kQueueRays + lane) * 2;
+                        slot[0] = make_float4(go.x, go.y, go.z, s2.x);
+                        slot[1] = make_float4(gd.x, gd.y, gd.z, bad ? __builtin_nanf("") : s2.y);  // seeds are in [0, 1)
+                    }
+                    if (lane == L) queued_end = bound;
+                }
+                if (filled) {
+                    // the records were written by other lanes of this wave: order the stores before the loads below
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
+                // (3) per lane: take the next ray.  (Fetching it a path ahead into LDS was tried and measured: no gain,
+                // the other waves of the SIMD already cover this load.)
+                if (alive && need_ray && have_item && ray < queued_end) {
+                    const float4 *slot = queue + ((size_t)lane * kQueueRays + (ray & (kQueueRays - 1))) * 2;
+                    const float4 ra = slot[0], rb = slot[1];
+                    ++ray;
+                    if (!__builtin_isnan(rb.w)) {  // else: the reference skips such a sample (it adds nothing)
+                        o = v3(ra.x, ra.y, ra.z);
+                        d = v3(rb.x, rb.y, rb.z);
+                        seed.x = ra.w;
+                        seed.y = rb.w;
+                        thr = v4(1, 1, 1, 1);
+                        fin = v4(0, 0, 0, 0);
+                        depth = 0;
+                        if (P.maxDepth > 0) need_ray = false;  // else color_ray's loop body never runs: the sample is (0,0,0,0)
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(alive && need_ray) == 0) break;
             }
         }
         prof.lap(0);
@@ -120,7 +164,7 @@ __global__ __launch_bounds__(KIND == kFetchMatrix ? 1024 : 256) void trace_kerne
                 fin = fin + thr * P.sky;                       // Shaders.metal:45
                 done = true;
             } else {
-                MatDev m = P.mats[obj];
+                MatDev m = fetch.material(P, obj);
                 fin = fin + thr * m.emis;                      // Shaders.metal:51-56
                 V4 att;
                 if (!scatter(m, d, o, hit, att, seed)) {       // Shaders.metal:60-62
@@ -385,7 +429,10 @@ size_t trace_lds_bytes(const TraceParams &P, int kind, int threads) {
     size_t bytes = (size_t)(threads / 64) * kMaskWordsPerWave * sizeof(uint32_t);
     if (kind == kFetchLds) bytes += (size_t)8 * (P.ngroups + 1) * sizeof(f4v);
     if (kind == kFetchStream) bytes += (size_t)(threads / 64) * 2 * kTileRecords * sizeof(f4v);
-    if (kind == kFetchMatrix) bytes += (size_t)((P.ngroups + 15) / 16) * 4096 + (size_t)4 * (P.ngroups + 1) * sizeof(f4v);
+    if (kind == kFetchMatrix) {
+        bytes += (size_t)((P.ngroups + 15) / 16) * 4096 + (size_t)4 * (P.ngroups + 1) * sizeof(f4v);
+        if (P.stage_mats) bytes += (size_t)8 * ((4 * (P.ngroups + 1) + 7) / 8) * sizeof(uint16_t) + (size_t)P.nobj * sizeof(MatDev);
+    }
     return bytes;
 }
 
