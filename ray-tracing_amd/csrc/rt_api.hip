@@ -621,7 +621,17 @@ RT_API int rt_render(rt_ctx *ctx, const Uniforms *u, const Object *objs, int obj
     // opt_chunk: > 0 as given, 0 = one item per pixel (the reference's sequential sum), < 0 = automatic: about 8
     // items per pixel, between 8 and 64 samples each, so that short launches still balance at the tail
     int chunk = ctx->opt_chunk;
-    if (chunk < 0) chunk = std::max(8, std::min(64, nrays / 8));
+    if (chunk < 0) {
+        chunk = std::max(8, std::min(64, nrays / 8));
+        // ... and at least about 16 items per lane the GPU can hold, so that the persistent grid drains evenly when
+        // the image or the sample count is small (each trip of a 100 000-sphere scene is long: a coarse tail costs 20 %)
+        const long long lanes = (long long)ctx->num_cus * 2048;
+        const long long cap = (long long)nrays * u->tileWidth * u->tileHeight / (16 * lanes);
+        // ... but not below the size at which drawing an item and generating its camera rays (one wave-wide batch
+        // per item) stops being small against tracing it: 4096 / spheres samples (small scenes keep the size above)
+        const long long floor_chunk = std::max(1, std::min(chunk, 4096 / std::max(1, ctx->nsph)));
+        chunk = (int)std::max(floor_chunk, std::min((long long)chunk, cap));
+    }
     if (chunk == 0 || chunk > nrays) chunk = nrays;
     const int nchunks = (nrays + chunk - 1) / chunk;
     const unsigned long long nitems = (unsigned long long)u->tileWidth * u->tileHeight * nchunks;
