@@ -327,6 +327,30 @@ def test_matrix_filter_scenes_bit_exact(rt, oracle, renderer, name, kw, w, h, sp
     assert np.array_equal(bits(img), bits(oracle.image(u, objs, w, h)))
 
 
+def test_matrix_and_vector_filters_agree_at_scale(rt, renderer):
+    """Larger than the oracle can check in seconds: 1200x675 at 96 spp (1.5e9 closest-hit searches), matrix-core
+    filter twice and vector filters once -- all three images must be the same bits."""
+    strict(renderer, rt, chunk=16)
+    w, h, spp = 1200, 675, 96
+    objs, n = rt.scene("cover")
+    u = rt.config_uniforms("cover", w, h, spp, 50, n)
+    renderer.setupTexture(w, h)
+    renderer.setScene(objs, n)
+    imgs = []
+    for filt in (0, 0, 2):
+        renderer.set_option(rt.RT_OPT_FILTER, filt)
+        try:
+            renderer.accumClear()
+            renderer.render(u, None, 0, 0, spp)
+            renderer.resolve(spp)
+            imgs.append(renderer.readTexture().copy())
+            assert renderer.lastStats().scene_path == (3 if filt == 0 else 0)
+        finally:
+            renderer.set_option(rt.RT_OPT_FILTER, 0)
+    assert np.array_equal(bits(imgs[0]), bits(imgs[1]))
+    assert np.array_equal(bits(imgs[0]), bits(imgs[2]))
+
+
 def test_default_path_of_the_cover_scene_is_the_matrix_filter(rt, renderer):
     strict(renderer, rt)
     objs, n = rt.scene("cover")
