@@ -306,16 +306,22 @@ RT_DEV void lift_ray(const LiftFrame &F, V3 o, V3 dn, float slack, float &oo, Ra
 // The four matrix instructions of a 32-sphere group are issued back to back and fenced off from the vector code
 // on both sides with scheduling barriers.  Letting the compiler weave the sign extraction of one group between
 // the matrix instructions of the next gave results that changed from run to run on MI355X (ROCm 7.2 compiler;
-// caught by rt_selftest_matrix_filter), so nothing but matrix instructions is in flight between the barriers,
-// and the results are read only after the whole group has been issued.
+// caught by rt_selftest_matrix_filter: its reference-side counts drift by a few hundred pairs in 3e8 although the
+// filter's own counts stay fixed; either barrier alone removes it, the cause was not isolated), so nothing but
+// matrix instructions is in flight between the barriers, and the results are read only after the whole group has
+// been issued.  -DRT_NO_MFMA_FENCE=0 builds without them, to reproduce.
 RT_DEV void matrix_group(const h8 a_lo, const h8 a_hi, const RayLifted &L, f32x16 &q0, f32x16 &q1) {
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#if !defined(RT_NO_MFMA_FENCE) || (RT_NO_MFMA_FENCE & 1)
     __builtin_amdgcn_sched_barrier(0);
+#endif
     q0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, L.b00, zero, 0, 0, 0);
     q1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, L.b10, zero, 0, 0, 0);
     q0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, L.b01, q0, 0, 0, 0);
     q1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, L.b11, q1, 0, 0, 0);
+#if !defined(RT_NO_MFMA_FENCE) || (RT_NO_MFMA_FENCE & 2)
     __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 
 RT_DEV uint32_t filter_round_matrix(const h8 *pm, int blk0, int blk1, uint32_t *masks, int lane, const RayLifted &L) {
