@@ -7,7 +7,7 @@ HIPFLAGS = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fas
 CFLAGS = -std=gnu11 -O2 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wextra
 
 HIP_SRCS = $(wildcard $(PKG)/csrc/*.hip)
-HIP_HDRS = $(wildcard $(PKG)/csrc/*.h) $(wildcard include/*.h)
+HIP_HDRS = $(wildcard $(PKG)/csrc/*.h) $(wildcard $(PKG)/csrc/*.hpp) $(wildcard include/*.h)
 
 all: $(LIBDIR)/librt_amd.so $(LIBDIR)/librt_host.so $(LIBDIR)/rt_render oracle
 
