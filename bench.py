@@ -41,6 +41,8 @@ def parse():
     p.add_argument("--filter", type=int, default=0, help="0 automatic (matrix cores where the scene allows), 1 general vector "
                    "filter, 2 vector filters only, 3 matrix cores whatever the scene size")
     p.add_argument("--blocks-per-cu", type=int, default=0)
+    p.add_argument("--partition", default="sample", choices=["sample", "tile"],
+                   help="N > 1: split the sample indices over the ranks (default), or rows of 64-pixel tiles (comparison)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo is for rehearsing N > 1 on fewer GPUs")
     p.add_argument("--cpu-spp", type=int, default=64, help="spp of the sub-sampled CPU baseline run")
@@ -117,7 +119,16 @@ def main():
     u = rt.config_uniforms(args.scene, W, H, spp, args.depth, n)
     r.setScene(objs, n)  # resident before the timed region
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
-    begin, end = part.ray_range(rank, world, spp)
+    if args.partition == "sample":
+        begin, end = part.ray_range(rank, world, spp)
+    else:
+        # every rank traces all samples of its own rows; the other rows of its buffer stay zero, so the same SUM
+        # reduce acts as the gather of disjoint tiles
+        begin, end = 0, spp
+        y0, y1 = part.tile_rows(rank, world, H)
+        u.tileY, u.tileHeight = y0, max(1, y1 - y0)
+        if y1 <= y0:
+            begin = end = 0  # more ranks than tile rows: nothing to trace
 
     def step():
         r.accumClear(accum.data_ptr())
@@ -196,7 +207,9 @@ def main():
                 "workload": "%s scene (%d spheres) %dx%d, %d spp, depth %d, one pass" % (args.scene, n, W, H, spp, args.depth),
                 "arithmetic": "hit decisions and radiance bit-identical to the uncontracted IEEE oracle",
                 "samples_per_rank": end - begin,
-                "parallelism": "sample-index split x%d, RCCL reduce of float4 accumulation buffers" % world,
+                "parallelism": ("sample-index split x%d, RCCL reduce of float4 accumulation buffers" % world)
+                               if args.partition == "sample" else
+                               ("rows of 64-pixel tiles split x%d, RCCL reduce as gather" % world),
             },
             "roofline": {
                 "bound": "valu_fp32",

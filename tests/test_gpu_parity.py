@@ -125,6 +125,34 @@ def test_sample_split_equals_one_call(rt, renderer):
     assert np.array_equal(bits(one), bits(two))
 
 
+def test_tile_row_split_equals_one_call(rt, renderer):
+    """The fallback partition: rows of 64-pixel tiles rendered by separate calls (ranks) into one buffer give the
+    bits of one call over the whole image -- a pixel's sum does not depend on which call traced it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rt_partition", os.path.join(HERE, "..", "ray-tracing_amd", "partition.py"))
+    part = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(part)
+    strict(renderer, rt, chunk=4)
+    w, h, spp = 200, 200, 8
+    objs, n = rt.scene("cover")
+    u = rt.config_uniforms("cover", w, h, spp, 50, n)
+    renderer.setupTexture(w, h)
+    one = renderer.renderImage(u, objs, n, chunk=4)
+    renderer.setScene(objs, n)
+    renderer.accumClear()
+    rows = []
+    for rank in range(3):
+        y0, y1 = part.tile_rows(rank, 3, h)
+        rows.append((y0, y1))
+        if y1 > y0:
+            u.tileY, u.tileHeight = y0, y1 - y0
+            renderer.render(u, None, 0, 0, spp)
+    assert rows[0][0] == 0 and rows[-1][1] == h and all(rows[i][1] == rows[i + 1][0] for i in range(2))
+    renderer.resolve(spp)
+    renderer.synchronize()
+    assert np.array_equal(bits(one), bits(renderer.readTexture()))
+
+
 def test_full_size_cover_spot_pixels(rt, oracle, renderer):
     """1200x675 cover configuration: 160 scattered pixels' linear sums against the oracle, bit for bit,
     plus run-to-run determinism of the whole frame."""
