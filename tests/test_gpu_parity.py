@@ -385,6 +385,48 @@ def test_matrix_and_vector_filters_agree_at_scale(rt, renderer):
     assert np.array_equal(bits(imgs[0]), bits(imgs[2]))
 
 
+def test_matrix_filter_awkward_spheres_bit_exact(rt, oracle, renderer):
+    """Spheres the lifted FP16 form cannot represent or that stress its rules, mixed into the cover scene: an exact
+    duplicate of an earlier sphere (equal distances: the lower index must win), radius 0, negative radius, NaN
+    radius, NaN centre, a huge enclosing sphere, a tiny sphere, one centred on the camera, one far outside the
+    frame, and an unknown object type.  Every filter choice must give the oracle's bits."""
+    strict(renderer, rt)
+    w, h, spp = 120, 68, 4
+    base, n0 = rt.scene("cover")
+    extra = []
+    dup = rt.Object.from_buffer_copy(base[40])
+    extra.append(dup)
+    glass = rt.SwiftMaterial.dielectric(1.5)
+    grey = rt.SwiftMaterial.lambertian(0.5, 0.5, 0.5)
+    extra.append(rt.makeSphere((1.0, 0.2, 1.0), 0.0, grey))
+    extra.append(rt.makeSphere((2.0, 0.5, -1.0), -0.5, glass))
+    extra.append(rt.makeSphere((3.0, 0.5, 1.0), float("nan"), grey))
+    extra.append(rt.makeSphere((float("nan"), 0.5, 1.0), 0.3, grey))
+    extra.append(rt.makeSphere((0.0, 0.0, 0.0), 400.0, glass))
+    extra.append(rt.makeSphere((5.0, 0.3, 1.5), 1e-4, grey))
+    extra.append(rt.makeSphere((13.0, 2.0, 3.0), 0.05, glass))
+    extra.append(rt.makeSphere((5000.0, 100.0, -3000.0), 50.0, grey))
+    odd = rt.makeSphere((-2.0, 0.4, 2.0), 0.4, grey)
+    odd.type = 9
+    extra.append(odd)
+    n = n0 + len(extra)
+    objs = (rt.Object * n)(*([base[i] for i in range(n0)] + extra))
+    u = rt.config_uniforms("cover", w, h, spp, 50, n)
+    renderer.setupTexture(w, h)
+    want = oracle.image(u, objs, w, h)
+    for filt, path in ((3, 3), (0, 3), (2, 0), (1, 0)):
+        renderer.set_option(rt.RT_OPT_FILTER, filt)
+        try:
+            img = renderer.renderImage(u, objs, n)
+            assert renderer.lastStats().scene_path == path
+        finally:
+            renderer.set_option(rt.RT_OPT_FILTER, 0)
+        assert np.array_equal(bits(img), bits(want)), filt
+    t4, ids = renderer.firstHit(u, objs, n)
+    want4, want_ids = oracle.first_hit(u, objs, w, h)
+    assert np.array_equal(ids, want_ids) and np.array_equal(bits(t4), bits(want4))
+
+
 def test_default_path_of_the_cover_scene_is_the_matrix_filter(rt, renderer):
     strict(renderer, rt)
     objs, n = rt.scene("cover")
