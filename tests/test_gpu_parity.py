@@ -427,6 +427,48 @@ def test_matrix_filter_awkward_spheres_bit_exact(rt, oracle, renderer):
     assert np.array_equal(ids, want_ids) and np.array_equal(bits(t4), bits(want4))
 
 
+@pytest.mark.parametrize("seed,extent,offset", [(1, 1.0, 0.0), (2, 20.0, 0.0), (3, 300.0, 0.0), (4, 20.0, 1000.0),
+                                                (5, 0.01, 0.0), (6, 3000.0, -7000.0)])
+def test_random_scenes_matrix_equals_vector(rt, renderer, seed, extent, offset):
+    """Random scenes over five decades of scale, at and far from the origin: the matrix-core filter and the
+    vector filters must give the same bits (the vector filters are checked against the oracle elsewhere)."""
+    strict(renderer, rt)
+    rng = np.random.default_rng(seed)
+    nsph = int(rng.integers(50, 400))
+    objs = []
+    for i in range(nsph):
+        c = offset + extent * (rng.random(3) - 0.5)
+        r = extent * 10.0 ** rng.uniform(-2.5, -1.0)
+        kind = rng.random()
+        if kind < 0.5:
+            m = rt.SwiftMaterial.lambertian(*rng.random(3))
+        elif kind < 0.75:
+            m = rt.SwiftMaterial.metal(*(0.5 + 0.5 * rng.random(3)), 0.5 * rng.random())
+        else:
+            m = rt.SwiftMaterial.dielectric(1.5)
+        objs.append(rt.makeSphere(tuple(float(v) for v in c), float(r), m))
+    arr = rt.object_array(objs)
+    w, h, spp = 96, 64, 4
+    u = rt.config_uniforms("cover", w, h, spp, 30, nsph)
+    f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+    centre = np.full(3, offset)
+    rt.host_lib().rt_camera_setup(C.byref(u), f3(centre + extent * np.array([1.2, 0.4, 0.9])), f3(centre), f3([0, 1, 0]), 40.0,
+                                  0.3, float(1.5 * extent), w, h)
+    renderer.setupTexture(w, h)
+    imgs = {}
+    for filt in (3, 2):
+        renderer.set_option(rt.RT_OPT_FILTER, filt)
+        try:
+            imgs[filt] = renderer.renderImage(u, arr, nsph)
+            path = renderer.lastStats().scene_path
+        finally:
+            renderer.set_option(rt.RT_OPT_FILTER, 0)
+        if filt == 3:
+            assert path == 3
+    assert np.array_equal(bits(imgs[3]), bits(imgs[2]))
+    assert len(np.unique(bits(imgs[3]).reshape(-1, 4), axis=0)) > 50   # the camera really sees the spheres
+
+
 def test_default_path_of_the_cover_scene_is_the_matrix_filter(rt, renderer):
     strict(renderer, rt)
     objs, n = rt.scene("cover")
