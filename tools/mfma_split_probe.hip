@@ -30,7 +30,7 @@ __global__ __launch_bounds__(512) void k(float *out, float seed, int do_mfma, in
             }
             for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i];
         }
-    } else if (do_valu) {
+    } else if (do_valu == 1) {
         float v[16];
         for (int i = 0; i < 16; ++i) v[i] = seed + i;
         for (int it = 0; it < ITERS; ++it) {
@@ -38,6 +38,14 @@ __global__ __launch_bounds__(512) void k(float *out, float seed, int do_mfma, in
             for (int i = 0; i < 32; ++i) v[i % 16] = __builtin_fmaf(v[i % 16], 0.999f, 0.001f);
         }
         for (int i = 0; i < 16; ++i) s += v[i];
+    } else if (do_valu == 2) {  // integer bit shuffling instead of floating point: v_alignbit_b32
+        unsigned v[16];
+        for (int i = 0; i < 16; ++i) v[i] = __float_as_uint(seed) + i * 77u + threadIdx.x;
+        for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) v[i % 16] = __builtin_amdgcn_alignbit(v[i % 16], v[(i + 1) % 16], 31);
+        }
+        for (int i = 0; i < 16; ++i) s += (float)v[i];
     }
     out[blockIdx.x * 512 + threadIdx.x] = s;
 }
@@ -69,6 +77,8 @@ int main() {
             double tm = run(out, blocks, 1, 0, cz), tv = run(out, blocks, 0, 1, cz), tb = run(out, blocks, 1, 1, cz);
             printf("%d workgroup(s)/CU, C operand %s: matrix waves alone %.3f ms, vector waves alone %.3f ms, together %.3f ms\n", per_cu,
                    cz ? "zero" : "accumulator", tm, tv, tb);
+            double ti = run(out, blocks, 0, 2, cz), tbi = run(out, blocks, 1, 2, cz);
+            printf("   the same with v_alignbit_b32 as the vector work: alone %.3f ms, together %.3f ms\n", ti, tbi);
         }
     return 0;
 }
