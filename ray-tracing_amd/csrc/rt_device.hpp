@@ -4,7 +4,7 @@
 // operation in the written order.  This file is compiled with -ffp-contract=off;
 // division and square root are hipcc's correctly rounded forms.  The only fused
 // multiply-adds in the library are the explicit __builtin_fmaf calls of the
-// conservative sphere filter in rt_kernels.hip, whose result never decides a hit.
+// conservative sphere filters in rt_hit.hpp (and the matrix instructions of rt_lift.hpp), whose results never decide a hit.
 // Metal built-ins are taken at their Metal Shading Language specification
 // formulas (dot = x*x'+y*y'+z*z' left to right, normalize = v / sqrt(dot(v,v)),
 // reflect = I - 2*dot(N,I)*N, refract with k = 1 - eta*eta*(1 - dot(N,I)^2),

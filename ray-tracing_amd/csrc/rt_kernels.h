@@ -20,7 +20,7 @@ struct TraceParams {
     // ---- hot ----
     const float4 *sphg;     // [nslots] strict records (cx, cy, cz, r): exact hit test and the general filter
                             //                 (padding: r = NaN, which can never hit)
-    const float4 *sphc;     // [nslots] compact filter records (cx, cy, cz, |c|^2 * (1 - 2^-17) - r*r * (1 + 2^-17))
+    const float4 *sphc;     // [nslots] compact filter records (cx, cy, cz, |c|^2 * (1 - 2^-16) - r*r * (1 + 2^-16))
     const int *sph_obj;     // [nslots] object index of each sphere slot; nslots = 4 * ngroups rounded up to a
                             //          multiple of 128, plus 256 spare never-hit slots (read-ahead of the fetchers)
     const QuadDev *quads;   // [nquad]
@@ -46,8 +46,8 @@ struct TraceParams {
     int chunk;              // samples per work item
     uint32_t nitems;        // tileW * tileH * ceil((ray_end - ray_begin) / chunk)
     uint32_t *counter;      // work-item counter, zeroed before the launch
-    unsigned long long *seg_counter;  // [0] += number of closest-hit searches; [1..6] += phase cycle stamps of the
-                                      // diagnostic instantiation
+    unsigned long long *seg_counter;  // [0] += number of closest-hit searches; [1..8] += phase cycle stamps and
+                                      // counts of the diagnostic instantiation
     float4 *planes;         // kModeAccum: [nchunks][width*height] partial sums, one plane per chunk
     float4 *target;         // kModeProgressive: rgba32Float render target
     int mode;
