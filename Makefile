@@ -3,7 +3,9 @@ HIPCC ?= /opt/rocm/bin/hipcc
 CC ?= gcc
 PKG = ray-tracing_amd
 LIBDIR = $(PKG)/lib
-HIPFLAGS = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fvisibility=hidden -Wall
+# -fno-slp-vectorize: packed FP32 instructions (v_pk_mul_f32, v_pk_add_f32) that the SLP vectoriser forms out of the
+# scalar per-lane arithmetic cost more than the two instructions they replace on gfx950 (matrix kind +3 %)
+HIPFLAGS = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fvisibility=hidden -Wall
 CFLAGS = -std=gnu11 -O2 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wextra
 
 HIP_SRCS = $(wildcard $(PKG)/csrc/*.hip)
