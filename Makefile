@@ -27,10 +27,16 @@ $(LIBDIR)/rt_render: $(PKG)/host/rt_cli.c $(PKG)/host/rt_renderer.c $(PKG)/host/
 oracle:
 	$(MAKE) -C oracle
 
+# instruction-rate and matrix-core probes behind the design (profiles/r01_*.txt are their outputs)
+TOOLS = tools/valu_rate tools/mfma_coexec tools/mfma_f16_probe tools/mfma_split_probe tools/op_rate
+tools: $(TOOLS)
+tools/%: tools/%.hip
+	$(HIPCC) --offload-arch=gfx950 -O3 -ffp-contract=off -o $@ $<
+
 host: $(LIBDIR)/librt_host.so
 
 clean:
 	rm -f $(LIBDIR)/*.so $(LIBDIR)/rt_render
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle host clean
+.PHONY: tools all oracle host clean
