@@ -45,6 +45,7 @@ struct Fetch;
 template <>
 struct Fetch<kFetchLds> {  // both arrays staged once per workgroup in LDS, read with a wave-uniform address (broadcast)
     static constexpr bool kMatrix = false;
+    static constexpr bool kScalarRecords = false;
     const f4v *pc, *pg, *p;
     RT_DEV void start(bool general) { p = general ? pg : pc; }
     RT_DEV void begin_word(int) {}
@@ -62,6 +63,7 @@ struct Fetch<kFetchLds> {  // both arrays staged once per workgroup in LDS, read
 template <>
 struct Fetch<kFetchScalar> {  // scalar cache: uniform address -> s_load_dwordx16 into scalar registers
     static constexpr bool kMatrix = false;
+    static constexpr bool kScalarRecords = true;
     const_f4_ptr pc, pg, p;
     const f4v *strict;
     RT_DEV void start(bool general) { p = general ? pg : pc; }
@@ -91,6 +93,7 @@ struct Fetch<kFetchScalar> {  // scalar cache: uniform address -> s_load_dwordx1
 template <>
 struct Fetch<kFetchStream> {
     static constexpr bool kMatrix = false;
+    static constexpr bool kScalarRecords = false;
     const f4v *gc, *gg, *src;
     f4v *tile;  // this wave's 2 x kTileRecords records
     f4v pre0, pre1;
@@ -129,6 +132,7 @@ struct Fetch<kFetchStream> {
 template <>
 struct Fetch<kFetchMatrix> {  // strict records and lifted A operands staged in LDS; the vector path is the general filter
     static constexpr bool kMatrix = true;
+    static constexpr bool kScalarRecords = false;
     const f4v *pg;
     const h8 *pm;        // [32-sphere group][K half][lane]
     const uint16_t *pobj;  // staged copies of sph_obj and mats, or null when they do not fit beside the rest
@@ -184,6 +188,39 @@ RT_DEV float sphere_q(f4v r, const RayCompact &y) {
     float cq = __builtin_fmaf(r.z, y.m2oz, __builtin_fmaf(r.y, y.m2oy, __builtin_fmaf(r.x, y.m2ox, r.w + y.oo1)));
     float bn = __builtin_fmaf(r.z, y.ndnz, __builtin_fmaf(r.y, y.ndny, __builtin_fmaf(r.x, y.ndnx, y.odn)));
     return __builtin_fmaf(bn, bn, -cq);
+}
+// The compact filter with its two accumulation chains (cq and bn) carried as the halves of packed FP32 registers:
+// four v_pk_fma_f32 instead of one add and six fused multiply-adds, the same operations in the same order, so the
+// same q bit for bit.  It pays where the record sits in scalar registers: a vector instruction with a scalar
+// source issues at half rate on gfx950 (4.2 clocks), and so does a packed one (4.3) -- which then does two.
+typedef float f2v __attribute__((ext_vector_type(2)));
+struct RayCompactPk { f2v one_zero, acc0, cx, cy, cz; };  // (1, 0), (oo1, o.dn), (-2ox, -dnx), (-2oy, -dny), (-2oz, -dnz)
+template <bool SCALAR>
+RT_DEV float sphere_q_packed(f4v r, const RayCompactPk &y) {
+    const f2v lo = {r.x, r.y}, hi = {r.z, r.w};
+    f2v t;
+    if constexpr (SCALAR) {
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(t) : "s"(hi), "v"(y.one_zero), "v"(y.acc0));
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(t) : "s"(lo), "v"(y.cx));
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(t) : "s"(lo), "v"(y.cy));
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(t) : "s"(hi), "v"(y.cz));
+    } else {
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(t) : "v"(hi), "v"(y.one_zero), "v"(y.acc0));
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(t) : "v"(lo), "v"(y.cx));
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(t) : "v"(lo), "v"(y.cy));
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(t) : "v"(hi), "v"(y.cz));
+    }
+    return __builtin_fmaf(t.y, t.y, -t.x);
+}
+RT_DEV float sphere_q(f4v r, const RayCompactPk &y) { return sphere_q_packed<true>(r, y); }
+RT_DEV RayCompactPk pack_compact(const RayCompact &c) {
+    RayCompactPk p;
+    p.one_zero = f2v{1.0f, 0.0f};
+    p.acc0 = f2v{c.oo1, c.odn};
+    p.cx = f2v{c.m2ox, c.ndnx};
+    p.cy = f2v{c.m2oy, c.ndny};
+    p.cz = f2v{c.m2oz, c.ndnz};
+    return p;
 }
 // (m << 1) | sign(q): sphere results enter the candidate word from the right.
 RT_DEV uint32_t push_sign(uint32_t m, float q) { return __builtin_amdgcn_alignbit(m, __float_as_uint(q), 31); }
@@ -403,7 +440,11 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
             y.odn = __builtin_fmaf(o.z, dn.z, __builtin_fmaf(o.y, dn.y, o.x * dn.x));
             y.m2ox = -2.0f * o.x; y.m2oy = -2.0f * o.y; y.m2oz = -2.0f * o.z;
             y.oo1 = oo * (1.0f - kCompactSlack);
-            nz = filter_round(f, g0, g1, P.nsph, wave_masks, lane, y);
+            if constexpr (F::kScalarRecords) {
+                nz = filter_round(f, g0, g1, P.nsph, wave_masks, lane, pack_compact(y));
+            } else {
+                nz = filter_round(f, g0, g1, P.nsph, wave_masks, lane, y);
+            }
         }
         if (!a_ok || !active) nz = 0;
         prof.lap(1);

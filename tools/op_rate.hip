@@ -69,6 +69,26 @@ KERNEL(k_cnd64, unsigned, UI, asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"
 KERNEL(k_accrd, unsigned, UI, asm volatile("v_accvgpr_read_b32 %0, a1" : "=v"(v[i])::"a1"))
 KERNEL(k_xor, unsigned, UI, asm volatile("v_xor_b32 %0, %0, %1" : "+v"(v[i]) : "v"(w)))
 KERNEL(k_lshl, unsigned, UI, asm volatile("v_lshlrev_b32 %0, %1, %0" : "+v"(v[i]) : "v"(w)))
+// packed FP32: two chains per 64-bit register pair
+#define KERNEL2(name, BODY)                                                              \
+    __global__ __launch_bounds__(256) void name(unsigned *out, unsigned seed) {           \
+        typedef float f2 __attribute__((ext_vector_type(2)));                             \
+        f2 v[CH], w = {FL(seed * 3u + threadIdx.x), FL(seed * 7u + threadIdx.x)};         \
+        f2 su = {FL(seed * 11u), FL(seed * 13u)};                                         \
+        for (int i = 0; i < CH; ++i) v[i] = f2{FL(seed + i * 977u + threadIdx.x), FL(seed + i * 31u)}; \
+        for (int it = 0; it < ITERS; ++it) {                                              \
+            _Pragma("unroll") for (int r = 0; r < REP; ++r)                               \
+                _Pragma("unroll") for (int i = 0; i < CH; ++i) { BODY; }                  \
+        }                                                                                 \
+        unsigned s = 0;                                                                   \
+        for (int i = 0; i < CH; ++i) s ^= __builtin_bit_cast(unsigned, v[i][0]) ^ __builtin_bit_cast(unsigned, v[i][1]); \
+        out[blockIdx.x * 256 + threadIdx.x] = s;                                          \
+    }
+KERNEL2(k_pkfma, asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(v[i]) : "v"(w), "v"(v[(i + 1) % CH])))
+KERNEL2(k_pkfma_s, asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(v[i]) : "s"(su), "v"(w)))
+KERNEL2(k_pkfma_sb, asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(v[i]) : "s"(su), "v"(w)))
+KERNEL2(k_pkmul, asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(v[i]) : "v"(w)))
+KERNEL2(k_pkadd, asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(v[i]) : "v"(w)))
 KERNEL(k_mov, unsigned, UI, asm volatile("v_mov_b32 %0, %1" : "+v"(v[i]) : "v"(w)))
 KERNEL(k_sad, unsigned, UI, asm volatile("v_sad_u32 %0, %0, %1, %1" : "+v"(v[i]) : "v"(w)))
 KERNEL(k_xad, unsigned, UI, asm volatile("v_xad_u32 %0, %0, %1, %1" : "+v"(v[i]) : "v"(w)))
@@ -109,7 +129,8 @@ int main() {
         {"v_mul_f32", k_mul, 1}, {"v_add_f32", k_addf, 1}, {"v_max_f32", k_maxf, 1}, {"v_sqrt_f32", k_sqrt, 1}, {"v_rcp_f32", k_rcp, 1},
         {"v_cvt_f32_u32", k_cvt, 1}, {"v_cvt_f16_f32", k_cvth, 1}, {"v_cmp_gt_f32 -> vcc", k_cmp32, 1},
         {"v_cmp_gt_f32 -> s[4:5]", k_cmp64, 1}, {"v_cndmask_b32 (sgpr pair)", k_cnd64, 1},
-        {"v_accvgpr_read_b32", k_accrd, 1}, {"v_xor_b32", k_xor, 1}, {"v_lshlrev_b32", k_lshl, 1}};
+        {"v_accvgpr_read_b32", k_accrd, 1}, {"v_pk_fma_f32 (2 fma)", k_pkfma, 1}, {"v_pk_fma_f32 s[pair], v, d", k_pkfma_s, 1},
+        {"v_pk_fma_f32 s(broadcast), v, d", k_pkfma_sb, 1}, {"v_pk_mul_f32", k_pkmul, 1}, {"v_pk_add_f32", k_pkadd, 1}, {"v_xor_b32", k_xor, 1}, {"v_lshlrev_b32", k_lshl, 1}};
     printf("%d waves per SIMD, %d chains per wave; clocks at a nominal 2.4 GHz\n", wps, CH);
     for (auto &t : tab) {
         double s = run(t.k, out, cus * wps);
