@@ -177,6 +177,39 @@ def test_full_size_cover_spot_pixels(rt, oracle, renderer):
     assert np.isfinite(img1).all() and img1.min() >= 0 and img1.max() <= 1 and (img1[..., 3] == 1).all()
 
 
+def test_bench_configuration_spot_pixels(rt, oracle, renderer):
+    """The configuration bench.py times -- cover scene, 1920x1080, 1000 spp, depth 50, default options (matrix-core
+    filter, 64 samples per work item) -- at 32 scattered pixels: each chunk's sequential sum, the chunks added in
+    order, mean, gamma, all recomputed by the oracle and compared bit for bit."""
+    for opt in (rt.RT_OPT_SCENE_FETCH, rt.RT_OPT_FILTER, rt.RT_OPT_BLOCKS_PER_CU):
+        renderer.set_option(opt, 0)
+    renderer.set_option(rt.RT_OPT_CHUNK, -1)
+    w, h, spp, chunk = 1920, 1080, 1000, 64
+    objs, n = rt.scene("cover")
+    u = rt.config_uniforms("cover", w, h, spp, 50, n)
+    renderer.setupTexture(w, h)
+    renderer.setScene(objs, n)
+    renderer.accumClear()
+    renderer.render(u, None, 0, 0, spp)
+    renderer.resolve(spp)
+    img = renderer.readTexture()
+    st = renderer.lastStats()
+    assert st.scene_path == 3 and st.samples == w * h * spp
+    rng = np.random.RandomState(11)
+    for _ in range(32):
+        x, y = int(rng.randint(0, w)), int(rng.randint(0, h))
+        acc = np.zeros(4, np.float32)
+        for b in range(0, spp, chunk):
+            part = np.zeros(4, np.float32)
+            for k in range(b, min(b + chunk, spp)):
+                c = (C.c_float * 4)()
+                if oracle.lib.rto_sample(C.byref(u), objs, x, y, k, c, None):
+                    part = part + np.array(list(c), np.float32)
+            acc = acc + part
+        want = oracle.resolve(acc.reshape(1, 1, 4), spp)[0, 0]
+        assert np.array_equal(bits(img[y, x]), bits(want)), (x, y)
+
+
 def test_4k_seed_rounding_spot_pixels(rt, oracle, renderer):
     """At 3840x2160 the integer seed expression exceeds 2^24 and is rounded on conversion to float."""
     strict(renderer, rt)
