@@ -331,7 +331,7 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
     int kind = ctx->opt_fetch == 2 ? 2 : (ctx->opt_fetch == 0 && 4 * P.ngroups <= kMaxLdsSpheres) ? 0 : 1;
     // Matrix-core filter: staged scenes the lifted form covers (rt_lift.hpp), from 48 spheres up -- below that the
     // fixed cost of lifting the ray outweighs the vector filter -- or any size when asked for with RT_OPT_FILTER 3.
-    if (kind == 0 && ctx->opt_kernel != 1 && ctx->oo_limit_m > 0.0f && 4 * P.ngroups <= kMaxMatrixSpheres &&
+    if (kind == 0 && ctx->oo_limit_m > 0.0f && 4 * P.ngroups <= kMaxMatrixSpheres &&
         ((ctx->opt_filter == 0 && ctx->nsph >= 48) || ctx->opt_filter == 3)) {
         kind = 3;
         P.oo_limit = ctx->oo_limit_m;
@@ -366,7 +366,9 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
         RT_TRY(grow(ctx, ctx->wf_pool, wavefront_pool_alloc_bytes((int)slots)));
         RT_HIP(hipEventRecord(ctx->ev0[slot], ctx->stream));
         int steps = 0;
-        RT_HIP(run_wavefront(P, kind == 0 ? 0 : 1, ctx->wf_pool.ptr, (int)slots, 4 * ctx->num_cus, ctx->stream, &steps));
+        const int wf_kind = kind == 3 ? 3 : (kind == 0 ? 0 : 1);
+        RT_HIP(run_wavefront(P, wf_kind, wf_kind == 3 ? threads : 256, ctx->wf_pool.ptr, (int)slots, per_cu * ctx->num_cus,
+                             ctx->stream, &steps));
         RT_HIP(hipEventRecord(ctx->ev1[slot], ctx->stream));
         blocks = slots / 256;
     } else {

@@ -62,8 +62,9 @@ void trace_launch_shape(const TraceParams &P, int fetch_kind, int *threads, int 
 size_t trace_lds_bytes(const TraceParams &P, int fetch_kind, int threads);
 // Wavefront formulation (rt_wavefront.hip): blocks until the launch is complete.
 size_t wavefront_pool_alloc_bytes(int slots);
-hipError_t run_wavefront(const TraceParams &P, int fetch_kind, void *pool, int slots, int extend_blocks, hipStream_t stream,
-                         int *steps_out);
+// fetch_kind 0, 1 or 3; extend_threads: workgroup size of the extend kernel (256, or what trace_launch_shape gives for 3).
+hipError_t run_wavefront(const TraceParams &P, int fetch_kind, int extend_threads, void *pool, int slots, int extend_blocks,
+                         hipStream_t stream, int *steps_out);
 hipError_t launch_first_hit(const TraceParams &P, float4 *out4, int *ids, hipStream_t stream);
 hipError_t launch_filter_selftest(uint32_t seed, int blocks, int pairs_per_thread, unsigned long long *out,
                                   hipStream_t stream);

@@ -165,17 +165,17 @@ __global__ __launch_bounds__(256) void wf_generate_kernel(const TraceParams P, c
     wave_push(W.q_ext[next], &W.cnt[next], live, slot);
 }
 
-// Each workgroup stages the scene once and then takes batches of 256 queue entries in a grid-stride loop.
+// Each workgroup stages the scene once and then takes batches of blockDim.x queue entries in a grid-stride loop.
 template <int KIND>
-__global__ __launch_bounds__(256) void wf_extend_kernel(const TraceParams P, const WfPool W, int cur) {
+__global__ __launch_bounds__(KIND == kFetchMatrix ? 1024 : 256) void wf_extend_kernel(const TraceParams P, const WfPool W, int cur) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_words[];
     const uint32_t n = W.cnt[cur];
-    if (blockIdx.x * 256u >= n) return;  // whole workgroup idle (uniform)
+    if (blockIdx.x * blockDim.x >= n) return;  // whole workgroup idle (uniform)
     uint32_t *wave_masks;
     Fetch<KIND> fetch;
     stage_scene<KIND>(P, lds_words, wave_masks, fetch);
     uint64_t nseg = 0;
-    for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
         const uint32_t i = base + threadIdx.x;
         const bool active = i < n;
         const uint32_t slot = active ? W.q_ext[cur][i] : 0u;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void wf_extend_kernel(const TraceParams P, con
         if (active && obj >= 0) {
             W.rec[(size_t)slot * kSlotVec4 + kHitA] = make_float4(hit.point.x, hit.point.y, hit.point.z, __int_as_float(obj));
             W.rec[(size_t)slot * kSlotVec4 + kHitB] = make_float4(hit.normal.x, hit.normal.y, hit.normal.z, hit.front ? 1.0f : 0.0f);
-            int type = P.mats[obj].type;
+            int type = fetch.material(P, obj).type;
             kind = type == 1 ? 1 : (type == 2 ? 2 : 0);
         }
         if (miss) {
@@ -285,15 +285,19 @@ size_t wavefront_pool_alloc_bytes(int slots) { return wavefront_pool_bytes(slots
 
 // Runs the whole launch: returns when every item is done (it has to read the queue counter back to know).
 // pool: device memory of wavefront_pool_alloc_bytes(slots) bytes.  steps_out: bounce steps executed.
-hipError_t run_wavefront(const TraceParams &P, int fetch_kind, void *pool, int slots, int extend_blocks, hipStream_t stream,
-                         int *steps_out) {
+hipError_t run_wavefront(const TraceParams &P, int fetch_kind, int extend_threads, void *pool, int slots, int extend_blocks,
+                         hipStream_t stream, int *steps_out) {
     WfPool W = carve_pool(pool, slots);
     const int blocks = (slots + 255) / 256;
-    const int ext_blocks = extend_blocks > 0 && extend_blocks < blocks ? extend_blocks : blocks;
+    const int ext_need = (slots + extend_threads - 1) / extend_threads;
+    const int ext_blocks = extend_blocks > 0 && extend_blocks < ext_need ? extend_blocks : ext_need;
     hipError_t e = hipMemsetAsync(W.cnt, 0, 256, stream);
     if (e != hipSuccess) return e;
-    size_t lds = (size_t)4 * kMaskWordsPerWave * sizeof(uint32_t) +
-                 (fetch_kind == kFetchLds ? (size_t)8 * (P.ngroups + 1) * sizeof(f4v) : 0);
+    const size_t lds = trace_lds_bytes(P, fetch_kind, extend_threads);
+    if (fetch_kind == kFetchMatrix && lds > 64 * 1024) {
+        e = hipFuncSetAttribute((const void *)wf_extend_kernel<kFetchMatrix>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     int cur = 0;
     hipLaunchKernelGGL(wf_generate_kernel, dim3(blocks), dim3(256), 0, stream, P, W, cur, 1);
     int steps = 0;
@@ -302,7 +306,9 @@ hipError_t run_wavefront(const TraceParams &P, int fetch_kind, void *pool, int s
     if (e != hipSuccess) return e;
     for (;;) {
         const int next = cur ^ 1;
-        if (fetch_kind == kFetchLds)
+        if (fetch_kind == kFetchMatrix)
+            hipLaunchKernelGGL(wf_extend_kernel<kFetchMatrix>, dim3(ext_blocks), dim3(extend_threads), lds, stream, P, W, cur);
+        else if (fetch_kind == kFetchLds)
             hipLaunchKernelGGL(wf_extend_kernel<kFetchLds>, dim3(ext_blocks), dim3(256), lds, stream, P, W, cur);
         else
             hipLaunchKernelGGL(wf_extend_kernel<kFetchScalar>, dim3(ext_blocks), dim3(256), lds, stream, P, W, cur);
