@@ -37,6 +37,8 @@ def parse():
     p.add_argument("--spp", type=int, default=1000)
     p.add_argument("--depth", type=int, default=50)
     p.add_argument("--chunk", type=int, default=-1, help="samples per work item (-1 = library default)")
+    p.add_argument("--tail-chunk", type=int, default=-1, help="samples per work item at the end of a launch (-1 = library default)")
+    p.add_argument("--tail-samples", type=int, default=-1, help="samples per pixel handed out in such short items (-1 = library default)")
     p.add_argument("--fetch", type=int, default=0, help="0 spheres in LDS, 1 scalar cache, 2 streamed")
     p.add_argument("--filter", type=int, default=0, help="0 automatic (matrix cores where the scene allows), 1 general vector "
                    "filter, 2 vector filters only, 3 matrix cores whatever the scene size")
@@ -112,6 +114,10 @@ def main():
     r.setupTexture(W, H)
     if args.chunk >= 0:
         r.set_option(rt.RT_OPT_CHUNK, args.chunk)
+    if args.tail_chunk >= 0:
+        r.set_option(rt.RT_OPT_TAIL_CHUNK, args.tail_chunk)
+    if args.tail_samples >= 0:
+        r.set_option(rt.RT_OPT_TAIL_SAMPLES, args.tail_samples)
     r.set_option(rt.RT_OPT_SCENE_FETCH, args.fetch)
     r.set_option(rt.RT_OPT_FILTER, args.filter)
     r.set_option(rt.RT_OPT_BLOCKS_PER_CU, args.blocks_per_cu)

@@ -49,7 +49,8 @@ enum {
 enum {
     RT_OPT_CHUNK = 1,       /* samples per work item of the batch path; 0 = all samples of a call in one
                                item, which reproduces the reference's sequential per-pixel sum order;
-                               -1 (default) = automatic, between 8 and 64 */
+                               -1 (default) = automatic: 1 to 64, from the samples per lane of the GPU and the
+                               scene size */
     RT_OPT_KERNEL = 3,      /* 0 = persistent kernel (default); 1 = wavefront formulation: generate / extend / shade
                                kernels over a pool of path slots with compacted queues (same results; rt_render then
                                returns only when the launch has finished); 2 = the persistent kernel with in-kernel
@@ -65,7 +66,12 @@ enum {
                                1 = always the translation-invariant 12-instruction vector filter,
                                2 = vector filters only (compact where the scene allows it),
                                3 = the matrix-core filter for any staged scene it covers, however small */
-    RT_OPT_WAVEFRONT_SLOTS = 7 /* path slots of the wavefront pool (default 2^20; 168 bytes of device memory each) */
+    RT_OPT_WAVEFRONT_SLOTS = 7, /* path slots of the wavefront pool (default 2^20; 168 bytes of device memory each) */
+    RT_OPT_TAIL_CHUNK = 8,  /* the last samples of every pixel are handed out in items of this many samples, after all
+                               longer items, so that the persistent grid drains evenly; 0 = no such tail;
+                               -1 (default) and 0 = no such tail (measured on the cover scene: it costs more in
+                               camera-ray generation than the even drain gains) */
+    RT_OPT_TAIL_SAMPLES = 9 /* samples per pixel in that tail; -1 (default) = automatic */
 };
 
 /* setupMetal (ContentView.swift:328-356): device, queue, pipelines.  `device` is the HIP device ordinal.
@@ -142,6 +148,10 @@ struct rt_stats {
     int block_threads;
     int scene_path;  /* how the last trace launch read and filtered the spheres: 0 staged in LDS + vector filter,
                         1 scalar cache + vector filter, 2 streamed + vector filter, 3 staged in LDS + matrix-core filter */
+    /* Work items of the last rt_render launch: the sample indices of a pixel were cut into chunk_count chunks of
+     * chunk samples followed by chunks of tail_chunk samples (the last one shorter if need be).  Each chunk is
+     * summed sample by sample, and the chunk sums are added in order. */
+    int chunk, chunk_count, tail_chunk;
     /* RT_OPT_KERNEL = 2 only, summed over waves, in shader clock cycles: [0] generate rays / draw work,
      * [1] sphere filter pass, [2] exact resolve of candidates, [3] quads + hit record, [4] shading,
      * [5] number of main-loop trips, [6] trips of the resolve loop, [7] candidates resolved, summed over lanes

@@ -81,10 +81,24 @@ class TileInfo(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("segments", C.c_uint64), ("tests", C.c_uint64), ("samples", C.c_uint64), ("kernel_ms", C.c_float),
                 ("grid_blocks", C.c_int), ("block_threads", C.c_int), ("scene_path", C.c_int),
-                ("phase_cycles", C.c_uint64 * 8)]
+                ("chunk", C.c_int), ("chunk_count", C.c_int), ("tail_chunk", C.c_int), ("phase_cycles", C.c_uint64 * 8)]
+
+    def chunk_ranges(self, ray_begin, ray_end):
+        """The sample ranges the last rt_render launch summed separately, in the order their sums are added."""
+        out, r = [], ray_begin
+        for i in range(self.chunk_count):
+            if r >= ray_end:
+                break
+            out.append((r, min(r + self.chunk, ray_end)))
+            r += self.chunk
+        while r < ray_end:
+            out.append((r, min(r + self.tail_chunk, ray_end)))
+            r += self.tail_chunk
+        return out
 
 
 RT_OPT_CHUNK, RT_OPT_KERNEL, RT_OPT_SCENE_FETCH, RT_OPT_BLOCKS_PER_CU, RT_OPT_FILTER, RT_OPT_WAVEFRONT_SLOTS = 1, 3, 4, 5, 6, 7
+RT_OPT_TAIL_CHUNK, RT_OPT_TAIL_SAMPLES = 8, 9
 
 # Every symbol include/rt_amd.h declares.
 AMD_SYMBOLS = [

@@ -57,7 +57,7 @@ struct rt_ctx {
     unsigned long long times_read = 0;  // launches already reported by rt_trace_times
     bool stats_pending = false;
 
-    int opt_chunk = -1;
+    int opt_chunk = -1, opt_tail_chunk = -1, opt_tail_samples = -1;
     int opt_kernel = 0;
     int opt_fetch = 0;
     int opt_blocks_per_cu = 0;
@@ -461,6 +461,14 @@ RT_API int rt_set_option(rt_ctx *ctx, int key, int value) {
             if (value < -1) return fail(ctx, RT_ERR_INVALID, "rt: chunk must be >= -1");
             ctx->opt_chunk = value;
             return RT_OK;
+        case RT_OPT_TAIL_CHUNK:
+            if (value < -1) return fail(ctx, RT_ERR_INVALID, "rt: tail chunk must be >= -1");
+            ctx->opt_tail_chunk = value;
+            return RT_OK;
+        case RT_OPT_TAIL_SAMPLES:
+            if (value < -1) return fail(ctx, RT_ERR_INVALID, "rt: tail samples must be >= -1");
+            ctx->opt_tail_samples = value;
+            return RT_OK;
         case RT_OPT_KERNEL:
             if (value < 0 || value > 2) return fail(ctx, RT_ERR_INVALID, "rt: kernel variant must be 0, 1 or 2");
             ctx->opt_kernel = value;
@@ -489,6 +497,8 @@ RT_API int rt_get_option(const rt_ctx *ctx, int key, int *value) {
     if (!ctx || !value) return RT_ERR_INVALID;
     switch (key) {
         case RT_OPT_CHUNK: *value = ctx->opt_chunk; return RT_OK;
+        case RT_OPT_TAIL_CHUNK: *value = ctx->opt_tail_chunk; return RT_OK;
+        case RT_OPT_TAIL_SAMPLES: *value = ctx->opt_tail_samples; return RT_OK;
         case RT_OPT_KERNEL: *value = ctx->opt_kernel; return RT_OK;
         case RT_OPT_SCENE_FETCH: *value = ctx->opt_fetch; return RT_OK;
         case RT_OPT_BLOCKS_PER_CU: *value = ctx->opt_blocks_per_cu; return RT_OK;
@@ -580,7 +590,8 @@ RT_API int rt_render_tile(rt_ctx *ctx, const Uniforms *u, const Object *objs, in
         P.tileX = u->tileX; P.tileY = u->tileY; P.tileW = tw; P.tileH = th;
         P.ray_begin = 0;
         P.ray_end = u->sampleCount > 0 ? u->sampleCount : 0;
-        P.chunk = P.ray_end > 0 ? P.ray_end : 1;
+        P.chunk = P.chunk_small = P.ray_end > 0 ? P.ray_end : 1;
+        P.nbig = 1;
         P.nitems = (uint32_t)tw * (uint32_t)th;
         P.mode = kModeProgressive;
         P.spp_pass = u->sampleCount;
@@ -620,23 +631,40 @@ RT_API int rt_render(rt_ctx *ctx, const Uniforms *u, const Object *objs, int obj
     if (ray_end == ray_begin) return RT_OK;
 
     const int nrays = ray_end - ray_begin;
-    // opt_chunk: > 0 as given, 0 = one item per pixel (the reference's sequential sum), < 0 = automatic: about 8
-    // items per pixel, between 8 and 64 samples each, so that short launches still balance at the tail
-    int chunk = ctx->opt_chunk;
+    // Work items: a pixel's samples are cut into `nbig` chunks of `chunk` samples followed by chunks of `small`
+    // samples, and items are handed out chunk by chunk.  opt_chunk > 0: chunk as given; 0: one item per pixel (the
+    // reference's sequential sum); < 0: automatic.
+    int chunk = ctx->opt_chunk, small = ctx->opt_tail_chunk, tail = ctx->opt_tail_samples;
+    const long long lanes = (long long)ctx->num_cus * 2048;
+    const long long pixels = (long long)u->tileWidth * u->tileHeight;
     if (chunk < 0) {
-        chunk = std::max(8, std::min(64, nrays / 8));
-        // ... and at least about 16 items per lane the GPU can hold, so that the persistent grid drains evenly when
-        // the image or the sample count is small (each trip of a 100 000-sphere scene is long: a coarse tail costs 20 %)
-        const long long lanes = (long long)ctx->num_cus * 2048;
-        const long long cap = (long long)nrays * u->tileWidth * u->tileHeight / (16 * lanes);
-        // ... but not below the size at which drawing an item and generating its camera rays (one wave-wide batch
-        // per item) stops being small against tracing it: 4096 / spheres samples (small scenes keep the size above)
-        const long long floor_chunk = std::max(1, std::min(chunk, 4096 / std::max(1, ctx->nsph)));
-        chunk = (int)std::max(floor_chunk, std::min((long long)chunk, cap));
+        // Long items leave lanes idle while the last ones finish -- a loss that grows with chunk / (samples per
+        // lane of the GPU); short items pay for drawing the item and for generating its camera rays (one wave-wide
+        // batch, however few rays) -- a loss that grows with 1 / (chunk x cost of tracing a sample), and that cost
+        // with the number of objects.  The minimum of the sum, with the constant fitted to measurements on the
+        // cover scene (32 at 1080p x 125 samples, 22 at 1080p x 64, 8 at 640x360 x 64); at most 64, one batch.
+        const double per_lane = (double)nrays * (double)pixels / (double)lanes;
+        const double objects = (double)std::max(1, ctx->nsph + ctx->nquad);
+        chunk = (int)std::lround(std::sqrt(1000.0 * per_lane / objects));
+        chunk = std::max(1, std::min(64, chunk));
     }
+    // A tail of short items after the long ones lets the grid drain more evenly, but on the cover scene it costs
+    // more in ray generation than it gains (1 to 2 %): off unless asked for.
+    if (small < 0) small = 0;
     if (chunk == 0 || chunk > nrays) chunk = nrays;
-    const int nchunks = (nrays + chunk - 1) / chunk;
-    const unsigned long long nitems = (unsigned long long)u->tileWidth * u->tileHeight * nchunks;
+    int nbig, nchunks;
+    if (small <= 0 || small >= chunk) {
+        small = chunk;
+        nbig = nchunks = (nrays + chunk - 1) / chunk;
+    } else {
+        // the short items must outlast the longest long item drawn just before them: a long item whose paths all
+        // run to the depth limit takes about 2.5 mean items, while the rest of the grid works through the tail
+        if (tail < 0) tail = (int)std::min<long long>(nrays / 2, (5 * (long long)chunk * lanes + 2 * pixels - 1) / (2 * pixels));
+        tail = std::min(tail, nrays);
+        nbig = (nrays - tail) / chunk;
+        nchunks = nbig + (nrays - nbig * chunk + small - 1) / small;
+    }
+    const unsigned long long nitems = (unsigned long long)pixels * nchunks;
     if (nitems > 0xF0000000ull) return fail(ctx, RT_ERR_TOO_LARGE, "rt: too many work items; raise RT_OPT_CHUNK");
     RT_TRY(grow(ctx, ctx->planes, (size_t)nchunks * ctx->width * ctx->height));
 
@@ -646,11 +674,16 @@ RT_API int rt_render(rt_ctx *ctx, const Uniforms *u, const Object *objs, int obj
     P.ray_begin = ray_begin;
     P.ray_end = ray_end;
     P.chunk = chunk;
+    P.nbig = nbig;
+    P.chunk_small = small;
     P.nitems = (uint32_t)nitems;
     P.mode = kModeAccum;
     P.planes = ctx->planes.ptr;
     RT_TRY(enqueue_trace(ctx, P));
     ctx->last.samples = (uint64_t)u->tileWidth * u->tileHeight * (uint64_t)nrays;
+    ctx->last.chunk = chunk;
+    ctx->last.chunk_count = nbig;
+    ctx->last.tail_chunk = small;
     float4 *acc = accum_dev ? (float4 *)accum_dev : ctx->accum.ptr;
     RT_HIP(launch_fold(acc, ctx->planes.ptr, nchunks, ctx->width, ctx->height, P.tileX, P.tileY, P.tileW, P.tileH,
                        ctx->stream));

@@ -137,8 +137,24 @@ struct Fetch<kFetchMatrix> {  // strict records and lifted A operands staged in 
     const h8 *pm;        // [32-sphere group][K half][lane]
     const uint16_t *pobj;  // staged copies of sph_obj and mats, or null when they do not fit beside the rest
     const MatDev *pmat;
-    RT_DEV int object_of(const TraceParams &P, int slot) const { return pobj ? pobj[slot] : P.sph_obj[slot]; }
-    RT_DEV MatDev material(const TraceParams &P, int obj) const { return pmat ? pmat[obj] : P.mats[obj]; }
+    // The staged copies are read through LDS-typed pointers: a load through a pointer that may be LDS or global is
+    // a flat load, which has to wait for every outstanding global memory operation of the wave as well as for LDS.
+    RT_DEV int object_of(const TraceParams &P, int slot) const {
+        if (pobj) return ((const __attribute__((address_space(3))) uint16_t *)pobj)[slot];
+        return P.sph_obj[slot];
+    }
+    RT_DEV MatDev material(const TraceParams &P, int obj) const {
+        typedef uint32_t __attribute__((may_alias)) word;
+        static_assert(sizeof(MatDev) % sizeof(word) == 0, "MatDev is copied word by word");
+        if (pmat) {
+            MatDev m;
+            const __attribute__((address_space(3))) word *src = (const __attribute__((address_space(3))) word *)(pmat + obj);
+            word *dst = (word *)&m;
+            for (unsigned i = 0; i < sizeof(MatDev) / sizeof(word); ++i) dst[i] = src[i];
+            return m;
+        }
+        return P.mats[obj];
+    }
     RT_DEV void start(bool) {}
     RT_DEV void begin_word(int) {}
     RT_DEV Rec4 load4(int group) const {
@@ -517,11 +533,21 @@ RT_DEV int world_hit(const TraceParams &P, F &f, uint32_t *wave_masks, bool acti
 
 // The parameter block as it lies in the kernel argument segment, behind a pointer the optimiser cannot see
 // through: loads of the cold fields stay where they are written instead of being hoisted to kernel entry and
-// held in scalar registers across the sphere loop.
-RT_DEV const TraceParams *cold_params() {
-    const TraceParams *p = (const TraceParams *)__builtin_amdgcn_kernarg_segment_ptr();
+// held in scalar registers across the sphere loop.  The pointer keeps the constant address space, so these loads
+// are scalar loads through the constant cache (as generic pointers they were per-lane flat loads, a memory round
+// trip each, one after the other).
+typedef const __attribute__((address_space(4))) TraceParams *ColdParams;
+RT_DEV ColdParams cold_params() {
+    ColdParams p = (ColdParams)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(p));
     return p;
+}
+RT_DEV Camera cold_camera(ColdParams C) {
+    Camera cam;
+    const __attribute__((address_space(4))) float *src = (const __attribute__((address_space(4))) float *)&C->cam;
+    float *dst = (float *)&cam;
+    for (unsigned i = 0; i < sizeof(Camera) / sizeof(float); ++i) dst[i] = src[i];
+    return cam;
 }
 
 // Dynamic LDS layout: [candidate words: waves x kMaskWordsPerWave] then, by fetch kind,

@@ -43,8 +43,10 @@ struct TraceParams {
     int tileX, tileY, tileW, tileH;
     int pass;               // Uniforms.currentSample
     int ray_begin, ray_end; // rayIndex range traced by this launch
-    int chunk;              // samples per work item
-    uint32_t nitems;        // tileW * tileH * ceil((ray_end - ray_begin) / chunk)
+    int chunk;              // samples per work item of the first `nbig` chunks of a pixel's sample range ...
+    int nbig, chunk_small;  // ... and of the chunks after them: items are drawn chunk by chunk, so the launch ends on
+                            // short items and the persistent grid drains evenly
+    uint32_t nitems;        // tileW * tileH * number of chunks
     uint32_t *counter;      // work-item counter, zeroed before the launch
     unsigned long long *seg_counter;  // [0] += number of closest-hit searches; [1..8] += phase cycle stamps and
                                       // counts of the diagnostic instantiation
@@ -53,6 +55,15 @@ struct TraceParams {
     int mode;
     int spp_pass;           // kModeProgressive: Uniforms.sampleCount
 };
+
+// Sample range [ray, ray_end) of chunk number `chunk` of a pixel.
+template <class ParamsPtr>
+__device__ __forceinline__ void chunk_range(ParamsPtr C, uint32_t chunk, int &ray, int &ray_end) {
+    const bool big = (int)chunk < C->nbig;
+    const int start = big ? (int)chunk * C->chunk : C->nbig * C->chunk + ((int)chunk - C->nbig) * C->chunk_small;
+    ray = C->ray_begin + start;
+    ray_end = min(ray + (big ? C->chunk : C->chunk_small), C->ray_end);
+}
 
 // fetch_kind: 0 records staged in LDS per workgroup, 1 scalar cache, 2 streamed through per-wave LDS tiles,
 // 3 staged in LDS with the matrix-core filter.  threads: workgroup size (256; kind 3 also 512 or 1024).

@@ -139,8 +139,7 @@ __global__ __launch_bounds__(256) void wf_generate_kernel(const TraceParams P, c
                 uint32_t ty = pix / (uint32_t)C->tileW;
                 px = (uint32_t)C->tileX + (pix - ty * (uint32_t)C->tileW);
                 py = (uint32_t)C->tileY + ty;
-                ray = C->ray_begin + (int)chunk * C->chunk;
-                ray_end = min(ray + C->chunk, C->ray_end);
+                chunk_range(C, chunk, ray, ray_end);
                 W.rec[(size_t)slot * kSlotVec4 + kAcc] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 have_item = true;
                 if (ray >= ray_end) continue;

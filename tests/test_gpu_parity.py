@@ -179,12 +179,13 @@ def test_full_size_cover_spot_pixels(rt, oracle, renderer):
 
 def test_bench_configuration_spot_pixels(rt, oracle, renderer):
     """The configuration bench.py times -- cover scene, 1920x1080, 1000 spp, depth 50, default options (matrix-core
-    filter, 64 samples per work item) -- at 32 scattered pixels: each chunk's sequential sum, the chunks added in
-    order, mean, gamma, all recomputed by the oracle and compared bit for bit."""
+    filter, automatic work items) -- at 32 scattered pixels: each chunk's sequential sum, the chunks added in order,
+    mean, gamma, all recomputed by the oracle and compared bit for bit."""
     for opt in (rt.RT_OPT_SCENE_FETCH, rt.RT_OPT_FILTER, rt.RT_OPT_BLOCKS_PER_CU):
         renderer.set_option(opt, 0)
-    renderer.set_option(rt.RT_OPT_CHUNK, -1)
-    w, h, spp, chunk = 1920, 1080, 1000, 64
+    for opt in (rt.RT_OPT_CHUNK, rt.RT_OPT_TAIL_CHUNK, rt.RT_OPT_TAIL_SAMPLES):
+        renderer.set_option(opt, -1)
+    w, h, spp = 1920, 1080, 1000
     objs, n = rt.scene("cover")
     u = rt.config_uniforms("cover", w, h, spp, 50, n)
     renderer.setupTexture(w, h)
@@ -195,13 +196,15 @@ def test_bench_configuration_spot_pixels(rt, oracle, renderer):
     img = renderer.readTexture()
     st = renderer.lastStats()
     assert st.scene_path == 3 and st.samples == w * h * spp
+    ranges = st.chunk_ranges(0, spp)
+    assert ranges[0][0] == 0 and ranges[-1][1] == spp and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
     rng = np.random.RandomState(11)
     for _ in range(32):
         x, y = int(rng.randint(0, w)), int(rng.randint(0, h))
         acc = np.zeros(4, np.float32)
-        for b in range(0, spp, chunk):
+        for b, e in ranges:
             part = np.zeros(4, np.float32)
-            for k in range(b, min(b + chunk, spp)):
+            for k in range(b, e):
                 c = (C.c_float * 4)()
                 if oracle.lib.rto_sample(C.byref(u), objs, x, y, k, c, None):
                     part = part + np.array(list(c), np.float32)
