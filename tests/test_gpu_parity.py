@@ -21,6 +21,8 @@ def strict(r, rt, chunk=0, fetch=0):
     r.set_option(rt.RT_OPT_SCENE_FETCH, fetch)
     r.set_option(rt.RT_OPT_FILTER, 0)
     r.set_option(rt.RT_OPT_CHUNK, chunk)
+    r.set_option(rt.RT_OPT_TAIL_CHUNK, -1)
+    r.set_option(rt.RT_OPT_TAIL_SAMPLES, -1)
     r.set_option(rt.RT_OPT_BLOCKS_PER_CU, 0)
 
 
@@ -105,6 +107,31 @@ def test_chunked_work_items_sum_in_chunk_order(rt, oracle, renderer):
     assert np.array_equal(bits(img), bits(oracle.resolve(acc, spp)))
     # and the result is within float-sum reordering distance of the reference's single sequential sum
     np.testing.assert_allclose(img, oracle.image(u, objs, w, h), atol=2e-6)
+
+
+def test_item_schedules_sum_in_the_reported_order(rt, oracle, renderer):
+    """Whatever the item schedule -- one-sample items, long items followed by a tail of short ones, the automatic
+    choice -- each reported range is summed sample by sample and the range sums are added in order."""
+    w, h, spp = 96, 54, 23
+    objs, n = rt.scene("cover")
+    u = rt.config_uniforms("cover", w, h, spp, 50, n)
+    renderer.setupTexture(w, h)
+    for chunk, tail_chunk, tail_samples in ((1, -1, -1), (7, 3, 8), (6, 2, -1), (-1, -1, -1), (-1, 1, 5)):
+        strict(renderer, rt, chunk=chunk)
+        renderer.set_option(rt.RT_OPT_TAIL_CHUNK, tail_chunk)
+        renderer.set_option(rt.RT_OPT_TAIL_SAMPLES, tail_samples)
+        img = renderer.renderImage(u, objs, n)
+        ranges = renderer.lastStats().chunk_ranges(0, spp)
+        assert ranges[0][0] == 0 and ranges[-1][1] == spp and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        if chunk == 1:
+            assert len(ranges) == spp
+        if 0 < tail_chunk < chunk:
+            assert ranges[-2][1] - ranges[-2][0] == tail_chunk and ranges[0][1] - ranges[0][0] > tail_chunk
+        acc = np.zeros((h, w, 4), np.float32)
+        for b, e in ranges:
+            acc = acc + oracle.accumulate(u, objs, w, h, b, e)
+        assert np.array_equal(bits(img), bits(oracle.resolve(acc, spp))), (chunk, tail_chunk, tail_samples)
+    strict(renderer, rt)
 
 
 def test_sample_split_equals_one_call(rt, renderer):
