@@ -181,7 +181,7 @@ def main():
         avg_trace_ms = sum(trace_ms) / max(1, len(trace_ms))
         flops_per_launch = FLOPS_PER_TEST * st.tests
         achieved = flops_per_launch / (avg_trace_ms * 1e-3) * 1e-12 if avg_trace_ms > 0 else 0.0
-        matrix = st.scene_path == 3
+        matrix = st.scene_path in (3, 4)
         # executed matrix work of one launch: every closest-hit search of a wave multiplies all sphere slots (padded
         # to 64) with the wave's 64 rays; lanes without a ray ride along, so count searches per lane slot
         slots64 = (n + 63) // 64 * 64
@@ -230,7 +230,8 @@ def main():
                          "not counted), so frac can exceed 1 against the FP32 vector peak") if matrix else
                         "achieved counts the reference's 23 flops per ray-object test",
                 "sphere_filter": {0: "vector, records staged in LDS", 1: "vector, scalar-cache fetch",
-                                  2: "vector, streamed tiles", 3: "matrix cores (v_mfma_f32_32x32x16_f16)"}[st.scene_path],
+                                  2: "vector, streamed tiles", 3: "matrix cores (v_mfma_f32_32x32x16_f16)",
+                                  4: "matrix cores, lifted tiles streamed through LDS"}[st.scene_path],
                 "mfma_executed": {"tflops": mfma_tflops, "peak": F16_MFMA_PEAK_TFLOPS,
                                   "frac": mfma_tflops / F16_MFMA_PEAK_TFLOPS} if matrix else None,
                 "flops_per_launch": flops_per_launch,

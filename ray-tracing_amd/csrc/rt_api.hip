@@ -40,6 +40,10 @@ struct rt_ctx {
     // compact scene
     DevBuf<float4> sph, sphc;
     DevBuf<_Float16> sphm;  // matrix-core filter: lifted A operands (rt_lift.hpp)
+    DevBuf<float4> tiles, tile_frames;  // tiled matrix-core kind (TraceParams::tiles)
+    DevBuf<int> tile_obj;
+    int ntiles = 0;
+    bool tiles_ok = false;     // every tile's frame covers its spheres and leaves room for ray origins
     LiftFrame lift = {0.0f, 0.0f, 0.0f, 1.0f};
     float oo_limit_m = -1.0f;  // origin limit of the matrix-core filter in the lifted frame; < 0: scene not eligible
     int matrix_outliers = 0;   // spheres the matrix-core filter always passes on to the exact test
@@ -131,6 +135,113 @@ int upload(rt_ctx *ctx, DevBuf<T> &b, const std::vector<T> &h) {
     RT_TRY(grow(ctx, b, h.size() ? h.size() : 1));
     if (!h.empty()) RT_HIP(hipMemcpyAsync(b.ptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     return RT_OK;
+}
+
+// Tiles of the tiled matrix-core kind (rt_hit.hpp, closest_sphere_tiled).  Spheres of ordinary size are sorted along
+// a Morton curve through their centres and cut into tiles of 512; each tile is lifted (rt_lift.hpp) in a frame
+// centred on the tile, with one power-of-two scale for the whole scene chosen so that a ray origin anywhere within
+// 1.5 scene diagonals of a tile stays inside the FP16 range of the lifted form.  Spheres that dwarf the rest (a
+// ground sphere) go last; no frame fits them, so their records make them candidates for every ray.
+struct TileSet {
+    std::vector<float4> tiles, frames;
+    std::vector<int> obj;
+    int ntiles = 0;
+    bool ok = false;
+};
+TileSet build_tiles(const std::vector<float4> &sph, const std::vector<int> &sph_obj, int nsph) {
+    TileSet T;
+    if (nsph <= 0) return T;
+    std::vector<float> radii;
+    for (int i = 0; i < nsph; ++i)
+        if (std::isfinite(sph[(size_t)i].w) && sph[(size_t)i].w > 0.0f) radii.push_back(sph[(size_t)i].w);
+    float rmed = 0.0f;
+    if (!radii.empty()) {
+        std::nth_element(radii.begin(), radii.begin() + (long)(radii.size() / 2), radii.end());
+        rmed = radii[radii.size() / 2];
+    }
+    auto regular = [&](int i) {
+        const float4 &q = sph[(size_t)i];
+        return std::isfinite(q.x) && std::isfinite(q.y) && std::isfinite(q.z) && std::isfinite(q.w) && q.w > 0.0f && q.w <= 64.0f * rmed;
+    };
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, rmax = 0.0;
+    int nreg = 0;
+    for (int i = 0; i < nsph; ++i) {
+        if (!regular(i)) continue;
+        const double c[3] = {sph[(size_t)i].x, sph[(size_t)i].y, sph[(size_t)i].z};
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], c[a]); hi[a] = std::max(hi[a], c[a]); }
+        rmax = std::max(rmax, (double)sph[(size_t)i].w);
+        ++nreg;
+    }
+    std::vector<std::pair<uint32_t, int>> keyed;
+    std::vector<int> order;
+    for (int i = 0; i < nsph; ++i) {
+        if (!regular(i)) continue;
+        const double c[3] = {sph[(size_t)i].x, sph[(size_t)i].y, sph[(size_t)i].z};
+        uint32_t key = 0;
+        uint32_t q[3];
+        for (int a = 0; a < 3; ++a) {
+            const double span = hi[a] - lo[a];
+            q[a] = span > 0.0 ? (uint32_t)std::min(1023.0, (c[a] - lo[a]) / span * 1024.0) : 0u;
+        }
+        for (int b = 9; b >= 0; --b)
+            for (int a = 0; a < 3; ++a) key = (key << 1) | ((q[a] >> b) & 1u);
+        keyed.push_back({key, -i});
+    }
+    // Equal keys (coincident spheres above all) in descending object order: the tie rule of the exact pass, not the
+    // visiting order, is what gives an equal distance to the lower index, and this keeps that rule exercised.
+    std::sort(keyed.begin(), keyed.end());
+    for (auto &kv : keyed) order.push_back(-kv.second);
+    for (int i = 0; i < nsph; ++i)
+        if (!regular(i)) order.push_back(i);
+    double diag = 0.0;
+    if (nreg > 0) {
+        for (int a = 0; a < 3; ++a) diag += (hi[a] - lo[a]) * (hi[a] - lo[a]);
+        diag = std::sqrt(diag) + 2.0 * rmax;
+    }
+    int ex = (diag > 0.0 && std::isfinite(diag)) ? (int)std::floor(std::log2(238.0 / (1.5 * diag))) : 0;
+    ex = std::max(-60, std::min(60, ex));
+    const float sigma = std::ldexp(1.0f, ex);
+    T.ntiles = (nsph + kTileSpheres - 1) / kTileSpheres;
+    T.tiles.assign((size_t)T.ntiles * kTileVec4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    T.frames.assign((size_t)T.ntiles * 2, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    T.obj.assign((size_t)T.ntiles * kTileSpheres, -1);
+    int outliers = 0;
+    for (int t = 0; t < T.ntiles; ++t) {
+        const int first = t * kTileSpheres, count = std::min(kTileSpheres, nsph - first);
+        double tlo[3] = {1e300, 1e300, 1e300}, thi[3] = {-1e300, -1e300, -1e300};
+        bool any = false;
+        for (int j = 0; j < count; ++j) {
+            const int i = order[(size_t)(first + j)];
+            if (!regular(i)) continue;
+            const double c[3] = {sph[(size_t)i].x, sph[(size_t)i].y, sph[(size_t)i].z};
+            for (int a = 0; a < 3; ++a) { tlo[a] = std::min(tlo[a], c[a]); thi[a] = std::max(thi[a], c[a]); }
+            any = true;
+        }
+        LiftFrame F = {0.0f, 0.0f, 0.0f, sigma};
+        if (any) { F.tx = (float)(0.5 * (tlo[0] + thi[0])); F.ty = (float)(0.5 * (tlo[1] + thi[1])); F.tz = (float)(0.5 * (tlo[2] + thi[2])); }
+        _Float16 *lifted = (_Float16 *)&T.tiles[(size_t)t * kTileVec4];
+        float4 *strict = &T.tiles[(size_t)t * kTileVec4 + kTileLifted];
+        for (int j = 0; j < kTileSpheres; ++j) {
+            _Float16 slots[kLiftSlots];
+            if (j < count) {
+                const int i = order[(size_t)(first + j)];
+                const float4 &q = sph[(size_t)i];
+                strict[j] = q;
+                T.obj[(size_t)(first + j)] = sph_obj[(size_t)i];
+                if (!lift_sphere(q.x, q.y, q.z, q.w, F, (double)kMfmaSlack, slots)) ++outliers;
+            } else {
+                strict[j] = make_float4(0.0f, 0.0f, 0.0f, std::numeric_limits<float>::quiet_NaN());  // never a hit
+                lift_constant(false, slots);
+            }
+            for (int k = 0; k < kLiftSlots; ++k) lifted[lift_index(j / 64, j % 64, k)] = slots[k];
+        }
+        // Origin limit in the tile's frame: the hard range limit of the lifted form.  The slack that grows with the
+        // distance of the origin only adds candidates; it is no reason to leave the matrix cores.
+        T.frames[(size_t)2 * t] = make_float4(F.tx, F.ty, F.tz, F.sigma);
+        T.frames[(size_t)2 * t + 1] = make_float4(57000.0f, (float)count, 0.0f, 0.0f);
+    }
+    T.ok = outliers <= std::max(2, nsph / 16);  // else pass B would do most of the work
+    return T;
 }
 
 // Object[] (160-byte AoS records) -> compact device arrays.  Sphere slots keep the objects' relative order;
@@ -254,6 +365,7 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n) {
             if (lim > 0.0) oo_limit_m = (float)lim;
         }
     }
+    TileSet tileset = build_tiles(sph, sph_obj, nsph);
     while ((int)sph.size() < nslots) {
         sph.push_back(make_float4(0.0f, 0.0f, 0.0f, std::numeric_limits<float>::quiet_NaN()));    // never a hit
         sphc.push_back(make_float4(0.0f, 0.0f, 0.0f, std::numeric_limits<float>::infinity()));    // q = -inf
@@ -262,6 +374,9 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n) {
     RT_TRY(upload(ctx, ctx->sph, sph));
     RT_TRY(upload(ctx, ctx->sphc, sphc));
     RT_TRY(upload(ctx, ctx->sphm, sphm));
+    RT_TRY(upload(ctx, ctx->tiles, tileset.tiles));
+    RT_TRY(upload(ctx, ctx->tile_frames, tileset.frames));
+    RT_TRY(upload(ctx, ctx->tile_obj, tileset.obj));
     RT_TRY(upload(ctx, ctx->sph_obj, sph_obj));
     RT_TRY(upload(ctx, ctx->quads, quads));
     RT_TRY(upload(ctx, ctx->mats, mats));
@@ -273,6 +388,8 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n) {
     ctx->lift = frame;
     ctx->oo_limit_m = oo_limit_m;
     ctx->matrix_outliers = outliers;
+    ctx->ntiles = tileset.ntiles;
+    ctx->tiles_ok = tileset.ok;
     ctx->nquad = (int)quads.size();
     ctx->nobj = n;
     return RT_OK;
@@ -312,6 +429,10 @@ void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
     P.nquad = ctx->nquad;
     P.oo_limit = ctx->opt_filter == 1 ? -1.0f : ctx->oo_limit;
     P.sphm = ctx->sphm.ptr;
+    P.tiles = ctx->tiles.ptr;
+    P.tile_frames = ctx->tile_frames.ptr;
+    P.tile_obj = ctx->tile_obj.ptr;
+    P.ntiles = ctx->ntiles;
     P.lift = ctx->lift;
     P.nobj = ctx->nobj;
     P.width = ctx->width;
@@ -328,7 +449,7 @@ void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
 int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
     // 0: staged in LDS when the scene fits, else scalar cache (measured faster than streaming on a 100 000-sphere
     // scene: 84 vs 78 TFLOP/s algorithmic); 1: scalar cache; 2: streamed through per-wave LDS tiles
-    int kind = ctx->opt_fetch == 2 ? 2 : (ctx->opt_fetch == 0 && 4 * P.ngroups <= kMaxLdsSpheres) ? 0 : 1;
+    int kind = ctx->opt_fetch == 2 ? 2 : ((ctx->opt_fetch == 0 || ctx->opt_fetch == 3) && 4 * P.ngroups <= kMaxLdsSpheres) ? 0 : 1;
     // Matrix-core filter: staged scenes the lifted form covers (rt_lift.hpp), from 48 spheres up -- below that the
     // fixed cost of lifting the ray outweighs the vector filter -- or any size when asked for with RT_OPT_FILTER 3.
     if (kind == 0 && ctx->oo_limit_m > 0.0f && 4 * P.ngroups <= kMaxMatrixSpheres &&
@@ -336,6 +457,10 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
         kind = 3;
         P.oo_limit = ctx->oo_limit_m;
     }
+    // Tiled matrix-core filter: scenes beyond the staged kinds whose tiles the lifted form covers, or when asked for.
+    if (ctx->ntiles > 0 && (ctx->opt_fetch == 3 || (ctx->opt_fetch == 0 && kind == 1 && ctx->tiles_ok &&
+                                                    (ctx->opt_filter == 0 || ctx->opt_filter == 3))))
+        kind = 4;
     int threads = 256, per_cu = 1;
     trace_launch_shape(P, kind, &threads, &per_cu);
     if (kind == 3) {
@@ -366,7 +491,7 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
         RT_TRY(grow(ctx, ctx->wf_pool, wavefront_pool_alloc_bytes((int)slots)));
         RT_HIP(hipEventRecord(ctx->ev0[slot], ctx->stream));
         int steps = 0;
-        const int wf_kind = kind == 3 ? 3 : (kind == 0 ? 0 : 1);
+        const int wf_kind = kind == 3 ? 3 : (kind == 0 ? 0 : 1);  // the tiled kind has no wavefront form: scalar cache
         RT_HIP(run_wavefront(P, wf_kind, wf_kind == 3 ? threads : 256, ctx->wf_pool.ptr, (int)slots, per_cu * ctx->num_cus,
                              ctx->stream, &steps));
         RT_HIP(hipEventRecord(ctx->ev1[slot], ctx->stream));
@@ -474,7 +599,7 @@ RT_API int rt_set_option(rt_ctx *ctx, int key, int value) {
             ctx->opt_kernel = value;
             return RT_OK;
         case RT_OPT_SCENE_FETCH:
-            if (value < 0 || value > 2) return fail(ctx, RT_ERR_INVALID, "rt: scene fetch must be 0, 1 or 2");
+            if (value < 0 || value > 3) return fail(ctx, RT_ERR_INVALID, "rt: scene fetch must be 0, 1, 2 or 3");
             ctx->opt_fetch = value;
             return RT_OK;
         case RT_OPT_BLOCKS_PER_CU:

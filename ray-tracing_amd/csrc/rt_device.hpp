@@ -174,6 +174,37 @@ RT_DEV bool sphere_root(float disc, float b, float a, float tmax, float &nbest, 
     return true;
 }
 
+// The same selection for spheres visited out of object order (the tiled kind sorts them in space).  The reference
+// visits objects in index order and keeps a later one only when strictly closer (Shaders.metal:21), i.e. it returns
+// the smallest accepted root and, among equal roots, the lowest object index -- and the root a sphere offers does
+// not depend on the order: if its first root is inside (kTMin, inf) but not below the current tmax, neither is its
+// second.  So roots up to and including tmax are let through here (tie = true when equal), and the caller settles a
+// tie by object index.  nskip is the numerator above which the quotient is certainly greater than tmax: nbest
+// (1 + 2^-22), four ulps, where the correctly rounded quotients by the same a can no longer coincide.
+RT_DEV bool sphere_root_any_order(float disc, float b, float a, float tmax, float nskip, float &n_out, float &root_out, bool &tie) {
+    if (disc < 0.0f) return false;
+    float sqrtd = __builtin_sqrtf(disc);
+    float n = -b - sqrtd;
+    bool ok = false;
+    float root = 0.0f;
+    if (n > 0.0f && n <= nskip) {
+        root = n / a;
+        ok = kTMin < root && root <= tmax;
+    }
+    if (!ok) {
+        n = -b + sqrtd;
+        if (n > 0.0f && n <= nskip) {
+            root = n / a;
+            ok = kTMin < root && root <= tmax;
+        }
+    }
+    if (!ok) return false;
+    n_out = n;
+    root_out = root;
+    tie = root == tmax;
+    return true;
+}
+
 // Lib.metal:248-280.  Interval is [kTMin, tmax] inclusive (Interval::contains).
 RT_DEV bool hit_quad(const QuadDev &q, V3 o, V3 d, float tmax, float &t_out, V3 &point, V3 &normal_out) {
     V3 n = cross(q.ex, q.ey);

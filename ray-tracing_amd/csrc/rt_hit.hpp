@@ -33,7 +33,10 @@ struct Rec4 { f4v r0, r1, r2, r3; };
 // load1(slot) -- the strict record (center, radius) of one sphere for pass B and the hit record.
 // kFetchMatrix is the staged kind with the matrix-core filter in place of the compact vector filter: strict
 // records and the lifted A operands (rt_lift.hpp) are staged in LDS.
-enum { kFetchLds = 0, kFetchScalar = 1, kFetchStream = 2, kFetchMatrix = 3 };
+// kFetchTiled is the matrix-core filter for scenes beyond that: the spheres are sorted along a space-filling curve
+// and cut into tiles of 512, each lifted in a frame of its own; a workgroup streams the tiles through two LDS
+// buffers (asynchronous global -> LDS copies), all its waves working on the same tile between two barriers.
+enum { kFetchLds = 0, kFetchScalar = 1, kFetchStream = 2, kFetchMatrix = 3, kFetchTiled = 4 };
 constexpr int kTileRecords = 128;  // kFetchStream: records per LDS tile (two tiles per wave)
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -45,6 +48,7 @@ struct Fetch;
 template <>
 struct Fetch<kFetchLds> {  // both arrays staged once per workgroup in LDS, read with a wave-uniform address (broadcast)
     static constexpr bool kMatrix = false;
+    static constexpr bool kTiled = false;
     static constexpr bool kScalarRecords = false;
     const f4v *pc, *pg, *p;
     RT_DEV void start(bool general) { p = general ? pg : pc; }
@@ -63,6 +67,7 @@ struct Fetch<kFetchLds> {  // both arrays staged once per workgroup in LDS, read
 template <>
 struct Fetch<kFetchScalar> {  // scalar cache: uniform address -> s_load_dwordx16 into scalar registers
     static constexpr bool kMatrix = false;
+    static constexpr bool kTiled = false;
     static constexpr bool kScalarRecords = true;
     const_f4_ptr pc, pg, p;
     const f4v *strict;
@@ -93,6 +98,7 @@ struct Fetch<kFetchScalar> {  // scalar cache: uniform address -> s_load_dwordx1
 template <>
 struct Fetch<kFetchStream> {
     static constexpr bool kMatrix = false;
+    static constexpr bool kTiled = false;
     static constexpr bool kScalarRecords = false;
     const f4v *gc, *gg, *src;
     f4v *tile;  // this wave's 2 x kTileRecords records
@@ -132,6 +138,7 @@ struct Fetch<kFetchStream> {
 template <>
 struct Fetch<kFetchMatrix> {  // strict records and lifted A operands staged in LDS; the vector path is the general filter
     static constexpr bool kMatrix = true;
+    static constexpr bool kTiled = false;
     static constexpr bool kScalarRecords = false;
     const f4v *pg;
     const h8 *pm;        // [32-sphere group][K half][lane]
@@ -164,6 +171,30 @@ struct Fetch<kFetchMatrix> {  // strict records and lifted A operands staged in 
     }
     RT_DEV void settle(Rec4 &) const {}
     RT_DEV f4v load1(int k) const { return pg[k]; }
+};
+
+template <>
+struct Fetch<kFetchTiled> {  // lifted tiles streamed through two LDS buffers per workgroup (closest_sphere_tiled)
+    static constexpr bool kMatrix = true;
+    static constexpr bool kTiled = true;
+    static constexpr bool kScalarRecords = false;
+    f4v *buf;            // LDS: two buffers of kTileVec4
+    const f4v *tiles;    // global
+    RT_DEV f4v load1(int k) const { return tiles[(size_t)(k / kTileSpheres) * kTileVec4 + kTileLifted + (k % kTileSpheres)]; }
+    RT_DEV int object_of(const TraceParams &P, int slot) const { return P.tile_obj[slot]; }
+    RT_DEV MatDev material(const TraceParams &P, int obj) const { return P.mats[obj]; }
+};
+
+// The strict records of one tile in LDS, with the interface filter_round expects.
+struct TileStrict {
+    const f4v *pg;
+    RT_DEV void begin_word(int) {}
+    RT_DEV Rec4 load4(int group) const {
+        const f4v *q = pg + 4 * group;
+        Rec4 r = {q[0], q[1], q[2], q[3]};
+        return r;
+    }
+    RT_DEV void settle(Rec4 &) const {}
 };
 
 // Optional in-kernel cycle stamps (diagnostic instantiation only): wave-level s_memtime differences summed
@@ -497,12 +528,109 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
     return ibest;
 }
 
+// Asynchronous copy of tile t into LDS buffer b: every wave of the workgroup copies 1 KiB pieces, each lane 16 bytes
+// (global_load_lds_dwordx4: per-lane global address, LDS address = wave-uniform base + 16 * lane).
+RT_DEV void tile_copy(const TraceParams &P, const Fetch<kFetchTiled> &f, int t, int b) {
+    const float4 *src = P.tiles + (size_t)t * kTileVec4 + (threadIdx.x & 63);
+    f4v *dst = f.buf + b * kTileVec4;
+    for (int u = (threadIdx.x >> 6) * 64; u < kTileVec4; u += (blockDim.x >> 6) * 64)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + u),
+                                         (__attribute__((address_space(3))) void *)(dst + u), 16, 0, 0);
+}
+
+// closest_sphere for the tiled kind.  Must be called by every wave of the workgroup the same number of times (it
+// contains workgroup barriers), after a workgroup barrier that follows the previous call (the first copy below
+// overwrites a buffer the previous call read).  Per tile: wait for the tile (the barrier also says that nobody
+// reads the other buffer any more), start the copy of the next tile into the other buffer, lift the rays into the
+// tile's frame, matrix-core filter over the tile's 8 blocks (or the general vector filter on the tile's strict
+// records when a ray of the wave starts outside the range of the tile's frame), exact pass B on the candidates.
+// Tiles hold the spheres in spatial order, not object order: ties in distance go to the lower object index
+// (sphere_root_any_order).  Returns the sphere slot in tile order.
+template <bool PROF>
+RT_DEV int closest_sphere_tiled(const TraceParams &P, Fetch<kFetchTiled> &f, uint32_t *wave_masks, bool active, V3 o, V3 d,
+                                float &tbest, Prof<PROF> &prof) {
+    const float a = dot(d, d);
+    const bool a_ok = !(__builtin_fabsf(a) < 1e-6f);  // Lib.metal:226-228
+    const float s = __builtin_amdgcn_rsqf(a) * kDirScale;
+    const V3 dn = v3(d.x * s, d.y * s, d.z * s);
+    const int lane = threadIdx.x & 63;
+    int ibest = -1;
+    float nskip = __builtin_inff();
+    tile_copy(P, f, 0, 0);
+    for (int t = 0; t < P.ntiles; ++t) {
+        __syncthreads();  // waits for this thread's copies first (the compiler drains vmcnt before the barrier)
+        if (t + 1 < P.ntiles) tile_copy(P, f, t + 1, (t + 1) & 1);
+        const f4v *tile = f.buf + (t & 1) * kTileVec4;
+        // scalar loads: a vector load here would make the wave wait for the copy it has just started
+        const const_f4_ptr frames = (const_f4_ptr)(uintptr_t)P.tile_frames;
+        const f4v fa = frames[2 * t], fb = frames[2 * t + 1];
+        const LiftFrame F = {fa.x, fa.y, fa.z, fa.w};
+        const int count = (int)fb.y;
+        float oo;
+        RayLifted lifted;
+        lift_ray(F, o, dn, kMfmaSlack, oo, lifted);
+        const bool general = __builtin_amdgcn_ballot_w64(active && !(oo <= fb.x)) != 0;  // wave-uniform
+        uint32_t nz;
+        if (general) {
+            RayGeneral y = {o, dn};
+            TileStrict ts = {tile + kTileLifted};
+            nz = filter_round(ts, 0, (count + 3) / 4, count, wave_masks, lane, y);
+        } else {
+            __builtin_amdgcn_s_setprio(0);
+            nz = filter_round_matrix((const h8 *)tile, 0, (count + 63) / 64, wave_masks, lane, lifted);
+            __builtin_amdgcn_s_setprio(1);
+        }
+        if (!a_ok || !active) nz = 0;
+        prof.lap(1);
+        uint32_t m = 0;
+        int w = 0;
+        for (;;) {
+            if (m == 0) {
+                if (nz == 0) break;
+                w = __builtin_ctz(nz);
+                nz &= nz - 1;
+                m = wave_masks[w * 64 + lane];
+            }
+            const int j = __builtin_clz(m);
+            m &= ~(0x80000000u >> j);
+            if constexpr (PROF) {
+                prof.count(6);
+                prof.count(7, (uint64_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)));
+            }
+            const int kl = w * 32 + j;
+            // Lib.metal:216-238 as written
+            f4v rec = tile[kTileLifted + kl];  // (center, radius)
+            float ocx = o.x - rec.x, ocy = o.y - rec.y, ocz = o.z - rec.z;
+            float b = ocx * d.x + ocy * d.y + ocz * d.z;
+            float c = (ocx * ocx + ocy * ocy + ocz * ocz) - rec.w * rec.w;
+            float disc = b * b - a * c;
+            float root, n;
+            bool tie;
+            if (sphere_root_any_order(disc, b, a, tbest, nskip, n, root, tie)) {
+                const int k = t * kTileSpheres + kl;
+                if (!tie || (ibest >= 0 && P.tile_obj[k] < P.tile_obj[ibest])) {
+                    tbest = root;
+                    ibest = k;
+                    nskip = n * (1.0f + 0x1p-22f);
+                }
+            }
+        }
+        prof.lap(2);
+    }
+    return ibest;
+}
+
 // Closest hit over spheres and quads; fills hit and returns the object index or -1.
 template <typename F, bool PROF>
 RT_DEV int world_hit(const TraceParams &P, F &f, uint32_t *wave_masks, bool active, V3 o, V3 d, Hit &hit, float &t_out,
                      Prof<PROF> &prof) {
     float tbest = kMaxFloat;
-    int slot = closest_sphere(P, f, wave_masks, active, o, d, tbest, prof);
+    int slot;
+    if constexpr (F::kTiled) {
+        slot = closest_sphere_tiled(P, f, wave_masks, active, o, d, tbest, prof);
+    } else {
+        slot = closest_sphere(P, f, wave_masks, active, o, d, tbest, prof);
+    }
     int obj = -1;
     if (slot >= 0) {
         obj = f.object_of(P, slot);
@@ -555,7 +683,8 @@ RT_DEV Camera cold_camera(ColdParams C) {
 //   kFetchStream: 4 waves x 2 tiles x kTileRecords x 16 B;
 //   kFetchScalar: nothing;
 //   kFetchMatrix: lifted A operands, 4 KiB per 64-sphere block, then strict records 4 * (ngroups + 1) x 16 B, then
-//                 (P.stage_mats) the slot -> object table (16-bit) and the material records.
+//                 (P.stage_mats) the slot -> object table (16-bit) and the material records;
+//   kFetchTiled:  two tile buffers of kTileVec4 x 16 B and four spare records (the vector filter reads one group ahead).
 template <int KIND>
 RT_DEV void stage_scene(const TraceParams &P, uint32_t *lds_words, uint32_t *&wave_masks, Fetch<KIND> &f) {
     const int wave = threadIdx.x >> 6;
@@ -591,6 +720,9 @@ RT_DEV void stage_scene(const TraceParams &P, uint32_t *lds_words, uint32_t *&wa
         f.pg = g;
         f.pobj = P.stage_mats ? ob : nullptr;
         f.pmat = P.stage_mats ? mt : nullptr;
+    } else if constexpr (KIND == kFetchTiled) {
+        f.buf = (f4v *)after_masks;
+        f.tiles = (const f4v *)P.tiles;
     } else if constexpr (KIND == kFetchScalar) {
         f.pc = (const_f4_ptr)(uintptr_t)P.sphc;
         f.pg = (const_f4_ptr)(uintptr_t)P.sphg;

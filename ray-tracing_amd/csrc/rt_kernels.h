@@ -12,6 +12,11 @@ namespace rt {
 enum { kModeAccum = 0, kModeProgressive = 1 };
 constexpr int kQueueRays = 64;  // camera rays per lane in the trace kernel's per-wave queue (two float4 each)
 
+// Tiled matrix-core kind (TraceParams::tiles, rt_hit.hpp closest_sphere_tiled).
+constexpr int kTileSpheres = 512;                      // sphere slots per tile = one resolve round
+constexpr int kTileLifted = kTileSpheres * 4;          // float4 of lifted A operands per tile (64 bytes per sphere)
+constexpr int kTileVec4 = kTileLifted + kTileSpheres;  // ... followed by the strict records
+
 // Everything one trace launch needs.  Passed by value in the kernel argument segment.  The first block is
 // read on every trip of the kernel's main loop and lives in scalar registers; the kernel reads the second
 // block (camera, work-item bookkeeping, output buffers) from the argument segment only where it is used, so
@@ -32,6 +37,11 @@ struct TraceParams {
                             // matrix-core filter the origin is measured in the lifted frame
     const void *sphm;       // matrix-core filter: lifted A operands, 4 KiB per 64-sphere block (rt_lift.hpp)
     LiftFrame lift;         // translation and scale of the lifted frame
+    const float4 *tiles;    // tiled matrix-core kind: per tile of 512 sphere slots, 2048 float4 of lifted A operands in
+                            // the tile's own frame, then the 512 strict records; slots are in tile (spatial) order
+    const float4 *tile_frames;  // per tile (tx, ty, tz, sigma), (origin limit in the tile's frame, spheres, 0, 0)
+    const int *tile_obj;    // [ntiles * 512] object index of each slot in tile order (-1: padding)
+    int ntiles;
     int stage_mats;         // matrix-core kind: sph_obj and mats are staged in LDS too (the launch reserved the room)
     int nobj;               // objects (length of mats)
     float4 *rayq;           // per-wave queues of generated camera rays: grid lanes x kQueueRays x 2 float4
@@ -66,7 +76,8 @@ __device__ __forceinline__ void chunk_range(ParamsPtr C, uint32_t chunk, int &ra
 }
 
 // fetch_kind: 0 records staged in LDS per workgroup, 1 scalar cache, 2 streamed through per-wave LDS tiles,
-// 3 staged in LDS with the matrix-core filter.  threads: workgroup size (256; kind 3 also 512 or 1024).
+// 3 staged in LDS with the matrix-core filter, 4 lifted tiles streamed through LDS per workgroup with the
+// matrix-core filter.  threads: workgroup size (256; kind 3 also 512 or 1024; kind 4 only 1024).
 hipError_t launch_trace(const TraceParams &P, int fetch_kind, bool profile, int blocks, int threads, hipStream_t stream);
 // Workgroup size and resident workgroups per compute unit that give the most resident waves.
 void trace_launch_shape(const TraceParams &P, int fetch_kind, int *threads, int *blocks_per_cu);

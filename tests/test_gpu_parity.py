@@ -83,14 +83,83 @@ def test_images_bit_exact(rt, oracle, renderer, name, w, h, spp, depth):
     assert np.array_equal(bits(img), bits(want))
 
 
-def test_scene_larger_than_lds_bit_exact(rt, oracle, renderer):
-    """5000 spheres exceed the LDS staging limit: the kernel reads them through the scalar cache."""
-    strict(renderer, rt)
+@pytest.mark.parametrize("fetch,path", [(0, 4), (1, 1), (2, 2)])
+def test_scene_larger_than_lds_bit_exact(rt, oracle, renderer, fetch, path):
+    """5000 spheres exceed the LDS staging limit: by default the workgroups stream lifted tiles through LDS (matrix-core
+    filter, spheres visited in spatial order); on request the records come through the scalar cache or per-wave tiles
+    (vector filter, object order).  All give the oracle's bits."""
+    strict(renderer, rt, fetch=fetch)
     objs, n = rt.scene("random_spheres", n=5000, extent=20.0)
     u = rt.config_uniforms("random_spheres", 96, 54, 2, 50, n)
     renderer.setupTexture(96, 54)
-    img = renderer.renderImage(u, objs, n)
+    try:
+        img = renderer.renderImage(u, objs, n)
+        assert renderer.lastStats().scene_path == path
+    finally:
+        strict(renderer, rt)
     assert np.array_equal(bits(img), bits(oracle.image(u, objs, 96, 54)))
+
+
+def test_tiled_matrix_filter_awkward_spheres_bit_exact(rt, oracle, renderer):
+    """The tiled kind sorts spheres in space, so equal hit distances are settled by an explicit rule instead of by the
+    visiting order.  3000 random spheres plus: exact duplicates of three of them appended at the end (the earlier
+    object must win although it is visited later), concentric shells sharing a centre, radius 0, negative radius, NaN
+    radius, NaN centre, a huge enclosing glass sphere and a far-away sphere -- against the oracle, and the scalar-cache
+    kind on the same scene."""
+    strict(renderer, rt)
+    w, h, spp = 96, 54, 3
+    base, n0 = rt.scene("random_spheres", n=3000, extent=12.0)
+    glass = rt.SwiftMaterial.dielectric(1.5)
+    red = rt.SwiftMaterial.lambertian(0.9, 0.1, 0.1)
+    extra = [rt.Object.from_buffer_copy(base[i]) for i in (7, 1500, 2999)]
+    for e in extra:
+        e.mat = red   # a different material: picking the wrong twin changes the image
+    extra.append(rt.makeSphere((0.5, 0.3, 0.5), 0.3, glass))
+    extra.append(rt.makeSphere((0.5, 0.3, 0.5), 0.2, red))
+    extra.append(rt.makeSphere((0.5, 0.3, 0.5), 0.3, red))
+    extra.append(rt.makeSphere((1.0, 0.2, 1.0), 0.0, red))
+    extra.append(rt.makeSphere((2.0, 0.5, -1.0), -0.5, glass))
+    extra.append(rt.makeSphere((3.0, 0.5, 1.0), float("nan"), red))
+    extra.append(rt.makeSphere((float("nan"), 0.5, 1.0), 0.3, red))
+    extra.append(rt.makeSphere((0.0, 0.0, 0.0), 300.0, glass))
+    extra.append(rt.makeSphere((5000.0, 100.0, -3000.0), 50.0, red))
+    n = n0 + len(extra)
+    objs = (rt.Object * n)(*([base[i] for i in range(n0)] + extra))
+    u = rt.config_uniforms("random_spheres", w, h, spp, 50, n)
+    renderer.setupTexture(w, h)
+    want = oracle.image(u, objs, w, h)
+    for fetch, path in ((0, 4), (3, 4), (1, 1)):
+        strict(renderer, rt, fetch=fetch)
+        try:
+            img = renderer.renderImage(u, objs, n)
+            assert renderer.lastStats().scene_path == path
+        finally:
+            strict(renderer, rt)
+        assert np.array_equal(bits(img), bits(want)), fetch
+
+
+def test_tiled_and_vector_filters_agree_on_100k_spheres(rt, renderer):
+    """The 100 000-sphere configuration at 640x360 x 4 spp, beyond what the oracle checks in seconds: streamed lifted
+    tiles (default) against the vector filter through the scalar cache, bit for bit, and run-to-run determinism."""
+    strict(renderer, rt, chunk=2)
+    w, h, spp = 640, 360, 4
+    objs, n = rt.scene("random_spheres")
+    u = rt.config_uniforms("random_spheres", w, h, spp, 50, n)
+    renderer.setupTexture(w, h)
+    renderer.setScene(objs, n)
+    imgs = []
+    for fetch, path in ((0, 4), (0, 4), (1, 1)):
+        strict(renderer, rt, chunk=2, fetch=fetch)
+        try:
+            renderer.accumClear()
+            renderer.render(u, None, 0, 0, spp)
+            renderer.resolve(spp)
+            imgs.append(renderer.readTexture().copy())
+            assert renderer.lastStats().scene_path == path
+        finally:
+            strict(renderer, rt)
+    assert np.array_equal(bits(imgs[0]), bits(imgs[1]))
+    assert np.array_equal(bits(imgs[0]), bits(imgs[2]))
 
 
 def test_chunked_work_items_sum_in_chunk_order(rt, oracle, renderer):
@@ -530,6 +599,13 @@ def test_random_scenes_matrix_equals_vector(rt, renderer, seed, extent, offset):
             assert path == 3
     assert np.array_equal(bits(imgs[3]), bits(imgs[2]))
     assert len(np.unique(bits(imgs[3]).reshape(-1, 4), axis=0)) > 50   # the camera really sees the spheres
+    renderer.set_option(rt.RT_OPT_SCENE_FETCH, 3)   # the same scene as one lifted tile in its own frame
+    try:
+        tiled = renderer.renderImage(u, arr, nsph)
+        assert renderer.lastStats().scene_path == 4
+    finally:
+        renderer.set_option(rt.RT_OPT_SCENE_FETCH, 0)
+    assert np.array_equal(bits(tiled), bits(imgs[2]))
 
 
 def test_default_path_of_the_cover_scene_is_the_matrix_filter(rt, renderer):
@@ -542,7 +618,7 @@ def test_default_path_of_the_cover_scene_is_the_matrix_filter(rt, renderer):
 
 
 @pytest.mark.parametrize("opt,val", [("RT_OPT_FILTER", 1), ("RT_OPT_FILTER", 2), ("RT_OPT_SCENE_FETCH", 1),
-                                     ("RT_OPT_SCENE_FETCH", 2), ("RT_OPT_KERNEL", 1)])
+                                     ("RT_OPT_SCENE_FETCH", 2), ("RT_OPT_SCENE_FETCH", 3), ("RT_OPT_KERNEL", 1)])
 def test_kernel_variants_bit_exact(rt, oracle, renderer, opt, val):
     """General-only filter, vector-only filters, scalar-cache fetch and streamed fetch give the same bits as the
     defaults."""
