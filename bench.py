@@ -39,7 +39,7 @@ def parse():
     p.add_argument("--chunk", type=int, default=-1, help="samples per work item (-1 = library default)")
     p.add_argument("--tail-chunk", type=int, default=-1, help="samples per work item at the end of a launch (-1 = library default)")
     p.add_argument("--tail-samples", type=int, default=-1, help="samples per pixel handed out in such short items (-1 = library default)")
-    p.add_argument("--fetch", type=int, default=0, help="0 spheres in LDS, 1 scalar cache, 2 streamed")
+    p.add_argument("--fetch", type=int, default=0, help="0 automatic, 1 scalar cache, 2 per-wave streamed tiles, 3 lifted tiles per workgroup (matrix cores)")
     p.add_argument("--filter", type=int, default=0, help="0 automatic (matrix cores where the scene allows), 1 general vector "
                    "filter, 2 vector filters only, 3 matrix cores whatever the scene size")
     p.add_argument("--blocks-per-cu", type=int, default=0)

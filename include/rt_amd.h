@@ -55,14 +55,20 @@ enum {
                                kernels over a pool of path slots with compacted queues (same results; rt_render then
                                returns only when the launch has finished); 2 = the persistent kernel with in-kernel
                                cycle stamps per phase (diagnostic; fills rt_stats.phase_cycles) */
-    RT_OPT_SCENE_FETCH = 4, /* where the sphere filter reads its records: 0 = staged in LDS once per workgroup and
-                               broadcast-read (default; scenes up to 1792 spheres, larger ones use 1),
-                               1 = through the scalar cache into scalar registers,
-                               2 = streamed from global memory through per-wave LDS tiles */
+    RT_OPT_SCENE_FETCH = 4, /* where the sphere filter reads its records:
+                               0 = automatic (default): staged in LDS once per workgroup and broadcast-read up to
+                                   1024 spheres (1792 with the vector filters); beyond that, 3 where the scene allows
+                                   it, else 1,
+                               1 = through the scalar cache into scalar registers (vector filter),
+                               2 = streamed from global memory through per-wave LDS tiles (vector filter),
+                               3 = spheres sorted in space and cut into tiles of 512, each lifted in a frame of its
+                                   own; every workgroup streams the tiles through two LDS buffers and runs the
+                                   matrix-core filter on them (any scene size) */
     RT_OPT_BLOCKS_PER_CU = 5, /* persistent grid size = this x compute units; 0 = occupancy query */
     RT_OPT_FILTER = 6,      /* which conservative sphere filter precedes the exact hit test; results are identical:
                                0 = automatic (default): the matrix-core filter for LDS-staged scenes of 48 to 1024
-                                   spheres that its FP16 range covers, else the compact 9-instruction vector filter,
+                                   spheres that its FP16 range covers and, tile by tile, for larger scenes
+                                   (RT_OPT_SCENE_FETCH 3); else the compact 9-instruction vector filter,
                                1 = always the translation-invariant 12-instruction vector filter,
                                2 = vector filters only (compact where the scene allows it),
                                3 = the matrix-core filter for any staged scene it covers, however small */
@@ -147,7 +153,8 @@ struct rt_stats {
     int grid_blocks;
     int block_threads;
     int scene_path;  /* how the last trace launch read and filtered the spheres: 0 staged in LDS + vector filter,
-                        1 scalar cache + vector filter, 2 streamed + vector filter, 3 staged in LDS + matrix-core filter */
+                        1 scalar cache + vector filter, 2 streamed + vector filter, 3 staged in LDS + matrix-core filter,
+                        4 lifted tiles streamed through LDS + matrix-core filter */
     /* Work items of the last rt_render launch: the sample indices of a pixel were cut into chunk_count chunks of
      * chunk samples followed by chunks of tail_chunk samples (the last one shorter if need be).  Each chunk is
      * summed sample by sample, and the chunk sums are added in order. */
