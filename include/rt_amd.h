@@ -187,6 +187,11 @@ RT_API int rt_selftest_filter(rt_ctx *ctx, uint32_t seed, int blocks, int pairs_
  * out[5] out-of-range spheres that were not handed on as candidates (must be 0). */
 RT_API int rt_selftest_matrix_filter(rt_ctx *ctx, uint32_t seed, int blocks, int rounds, int slack_log2, uint64_t out[6]);
 
+/* No counterpart in the reference.  The same check for the form the tiled kind (RT_OPT_SCENE_FETCH 3) lifts its rays
+ * in: the frame is local to the 64 spheres while the rays start up to 2^20 radii away.  slack_log2 scales both the
+ * relative slack and the distance-dependent one; -16 is what the library renders with.  Same outputs. */
+RT_API int rt_selftest_tiled_filter(rt_ctx *ctx, uint32_t seed, int blocks, int rounds, int slack_log2, uint64_t out[6]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,7 +105,7 @@ AMD_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_option", "rt_get_option", "rt_set_target", "rt_clear",
     "rt_write_target", "rt_read_target", "rt_render_tile", "rt_present_bgra8", "rt_set_scene", "rt_render",
     "rt_accum_clear", "rt_accum_ptr", "rt_resolve", "rt_synchronize", "rt_first_hit", "rt_last_stats", "rt_trace_times",
-    "rt_selftest_filter", "rt_selftest_matrix_filter",
+    "rt_selftest_filter", "rt_selftest_matrix_filter", "rt_selftest_tiled_filter",
 ]
 HOST_SYMBOLS = [
     "rt_material_default", "rt_material_lambertian", "rt_material_metal", "rt_material_dielectric", "rt_material_light",
@@ -148,6 +148,7 @@ def amd_lib():
         lib.rt_trace_times.argtypes = [vp, vp, ip, C.POINTER(ip)]
         lib.rt_selftest_filter.argtypes = [vp, C.c_uint32, ip, ip, vp]
         lib.rt_selftest_matrix_filter.argtypes = [vp, C.c_uint32, ip, ip, ip, vp]
+        lib.rt_selftest_tiled_filter.argtypes = [vp, C.c_uint32, ip, ip, ip, vp]
         _amd = lib
     return _amd
 
@@ -457,6 +458,11 @@ class MetalRenderer:
     def selftestMatrixFilter(self, seed=1, blocks=1024, rounds=64, slack_log2=-16):
         out = (C.c_uint64 * 6)()
         self._check(self._lib.rt_selftest_matrix_filter(self._ctx, seed, blocks, rounds, slack_log2, out))
+        return dict(zip(["pairs", "reference", "matrix", "missed", "out_of_range", "unflagged"], list(out)))
+
+    def selftestTiledFilter(self, seed=1, blocks=1024, rounds=64, slack_log2=-16):
+        out = (C.c_uint64 * 6)()
+        self._check(self._lib.rt_selftest_tiled_filter(self._ctx, seed, blocks, rounds, slack_log2, out))
         return dict(zip(["pairs", "reference", "matrix", "missed", "out_of_range", "unflagged"], list(out)))
 
     def renderImage(self, u, objs, n, chunk=None):

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <string>
 #include <vector>
@@ -137,16 +138,64 @@ int upload(rt_ctx *ctx, DevBuf<T> &b, const std::vector<T> &h) {
     return RT_OK;
 }
 
-// Tiles of the tiled matrix-core kind (rt_hit.hpp, closest_sphere_tiled).  Spheres of ordinary size are sorted along
-// a Morton curve through their centres and cut into tiles of 512; each tile is lifted (rt_lift.hpp) in a frame
-// centred on the tile, with one power-of-two scale for the whole scene chosen so that a ray origin anywhere within
-// 1.5 scene diagonals of a tile stays inside the FP16 range of the lifted form.  Spheres that dwarf the rest (a
-// ground sphere) go last; no frame fits them, so their records make them candidates for every ray.
+// Tiles of the tiled matrix-core kind (rt_hit.hpp, closest_sphere_tiled).  Spheres of ordinary size are partitioned
+// by recursive median splits along the longest axis of their centres' bounding box into tiles of at most 512 that
+// are also small against their spheres -- half-diagonal <= 128 median radii, so that a sphere's own share of the
+// lifted form's relative slack, 2^-16 |c'|^2, stays below a quarter of r^2 (down to 64 spheres per tile in sparse
+// scenes).  Each tile is lifted (rt_lift.hpp) in a frame centred on the tile, with one power-of-two scale for the
+// whole scene chosen so that any line passing within 1.5 scene diagonals of a tile's centre stays inside the FP16
+// range.  Spheres that dwarf the rest (a ground sphere) ride in the last tile; no frame fits them, so their records
+// make them candidates for every ray.
 struct TileSet {
     std::vector<float4> tiles, frames;
     std::vector<int> obj;
     int ntiles = 0;
     bool ok = false;
+};
+struct TileBuilder {
+    const std::vector<float4> &sph;
+    std::vector<int> ids;                       // regular spheres, permuted in place
+    std::vector<std::pair<int, int>> leaves;    // [begin, end) into ids
+    void split(int begin, int end) {
+        const int n = end - begin;
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        std::vector<float> radii;
+        for (int i = begin; i < end; ++i) {
+            const float4 &q = sph[(size_t)ids[(size_t)i]];
+            const double c[3] = {q.x, q.y, q.z};
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], c[a]); hi[a] = std::max(hi[a], c[a]); }
+            radii.push_back(q.w);
+        }
+        std::nth_element(radii.begin(), radii.begin() + n / 2, radii.end());
+        const double rmed = radii[(size_t)(n / 2)];
+        double diag2 = 0.0;
+        int axis = 0;
+        for (int a = 0; a < 3; ++a) {
+            diag2 += (hi[a] - lo[a]) * (hi[a] - lo[a]);
+            if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
+        }
+        const bool compact = 0.5 * std::sqrt(diag2) <= 128.0 * rmed;
+        if (n <= 64 || (n <= kTileSpheres && compact)) {
+            leaves.push_back({begin, end});
+            return;
+        }
+        // full tiles on the left as long as the count decides; halves rounded to whole 64-sphere blocks below that
+        int left;
+        if (n > kTileSpheres) {
+            const int nt = (n + kTileSpheres - 1) / kTileSpheres;
+            left = (nt / 2) * kTileSpheres;
+        } else {
+            left = ((n / 2 + 63) / 64) * 64;
+        }
+        auto less = [&](int x, int y) {
+            const float4 &p = sph[(size_t)x], &q = sph[(size_t)y];
+            const float u = axis == 0 ? p.x : (axis == 1 ? p.y : p.z), v = axis == 0 ? q.x : (axis == 1 ? q.y : q.z);
+            return u < v || (u == v && x < y);
+        };
+        std::nth_element(ids.begin() + begin, ids.begin() + begin + left, ids.begin() + end, less);
+        split(begin, begin + left);
+        split(begin + left, end);
+    }
 };
 TileSet build_tiles(const std::vector<float4> &sph, const std::vector<int> &sph_obj, int nsph) {
     TileSet T;
@@ -163,55 +212,51 @@ TileSet build_tiles(const std::vector<float4> &sph, const std::vector<int> &sph_
         const float4 &q = sph[(size_t)i];
         return std::isfinite(q.x) && std::isfinite(q.y) && std::isfinite(q.z) && std::isfinite(q.w) && q.w > 0.0f && q.w <= 64.0f * rmed;
     };
+    TileBuilder B{sph, {}, {}};
+    std::vector<int> irregular;
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, rmax = 0.0;
-    int nreg = 0;
     for (int i = 0; i < nsph; ++i) {
-        if (!regular(i)) continue;
+        if (!regular(i)) {
+            irregular.push_back(i);
+            continue;
+        }
+        B.ids.push_back(i);
         const double c[3] = {sph[(size_t)i].x, sph[(size_t)i].y, sph[(size_t)i].z};
         for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], c[a]); hi[a] = std::max(hi[a], c[a]); }
         rmax = std::max(rmax, (double)sph[(size_t)i].w);
-        ++nreg;
     }
-    std::vector<std::pair<uint32_t, int>> keyed;
-    std::vector<int> order;
-    for (int i = 0; i < nsph; ++i) {
-        if (!regular(i)) continue;
-        const double c[3] = {sph[(size_t)i].x, sph[(size_t)i].y, sph[(size_t)i].z};
-        uint32_t key = 0;
-        uint32_t q[3];
-        for (int a = 0; a < 3; ++a) {
-            const double span = hi[a] - lo[a];
-            q[a] = span > 0.0 ? (uint32_t)std::min(1023.0, (c[a] - lo[a]) / span * 1024.0) : 0u;
-        }
-        for (int b = 9; b >= 0; --b)
-            for (int a = 0; a < 3; ++a) key = (key << 1) | ((q[a] >> b) & 1u);
-        keyed.push_back({key, -i});
-    }
-    // Equal keys (coincident spheres above all) in descending object order: the tie rule of the exact pass, not the
+    if (!B.ids.empty()) B.split(0, (int)B.ids.size());
+    // tile contents in slot order.  Inside a tile: descending object index -- the tie rule of the exact pass, not the
     // visiting order, is what gives an equal distance to the lower index, and this keeps that rule exercised.
-    std::sort(keyed.begin(), keyed.end());
-    for (auto &kv : keyed) order.push_back(-kv.second);
-    for (int i = 0; i < nsph; ++i)
-        if (!regular(i)) order.push_back(i);
+    std::vector<std::vector<int>> members;
+    for (auto &lf : B.leaves) {
+        std::vector<int> m(B.ids.begin() + lf.first, B.ids.begin() + lf.second);
+        std::sort(m.begin(), m.end(), std::greater<int>());
+        members.push_back(m);
+    }
+    for (int i : irregular) {
+        if (members.empty() || (int)members.back().size() >= kTileSpheres) members.push_back({});
+        members.back().push_back(i);
+    }
     double diag = 0.0;
-    if (nreg > 0) {
+    if (!B.ids.empty()) {
         for (int a = 0; a < 3; ++a) diag += (hi[a] - lo[a]) * (hi[a] - lo[a]);
         diag = std::sqrt(diag) + 2.0 * rmax;
     }
     int ex = (diag > 0.0 && std::isfinite(diag)) ? (int)std::floor(std::log2(238.0 / (1.5 * diag))) : 0;
     ex = std::max(-60, std::min(60, ex));
     const float sigma = std::ldexp(1.0f, ex);
-    T.ntiles = (nsph + kTileSpheres - 1) / kTileSpheres;
+    T.ntiles = (int)members.size();
     T.tiles.assign((size_t)T.ntiles * kTileVec4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     T.frames.assign((size_t)T.ntiles * 2, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     T.obj.assign((size_t)T.ntiles * kTileSpheres, -1);
     int outliers = 0;
     for (int t = 0; t < T.ntiles; ++t) {
-        const int first = t * kTileSpheres, count = std::min(kTileSpheres, nsph - first);
+        const std::vector<int> &m = members[(size_t)t];
+        const int count = (int)m.size();
         double tlo[3] = {1e300, 1e300, 1e300}, thi[3] = {-1e300, -1e300, -1e300};
         bool any = false;
-        for (int j = 0; j < count; ++j) {
-            const int i = order[(size_t)(first + j)];
+        for (int i : m) {
             if (!regular(i)) continue;
             const double c[3] = {sph[(size_t)i].x, sph[(size_t)i].y, sph[(size_t)i].z};
             for (int a = 0; a < 3; ++a) { tlo[a] = std::min(tlo[a], c[a]); thi[a] = std::max(thi[a], c[a]); }
@@ -221,24 +266,31 @@ TileSet build_tiles(const std::vector<float4> &sph, const std::vector<int> &sph_
         if (any) { F.tx = (float)(0.5 * (tlo[0] + thi[0])); F.ty = (float)(0.5 * (tlo[1] + thi[1])); F.tz = (float)(0.5 * (tlo[2] + thi[2])); }
         _Float16 *lifted = (_Float16 *)&T.tiles[(size_t)t * kTileVec4];
         float4 *strict = &T.tiles[(size_t)t * kTileVec4 + kTileLifted];
+        double cmax = 0.0;  // largest |c'| among the spheres of the tile that are filtered (lift_ray_near)
         for (int j = 0; j < kTileSpheres; ++j) {
             _Float16 slots[kLiftSlots];
             if (j < count) {
-                const int i = order[(size_t)(first + j)];
+                const int i = m[(size_t)j];
                 const float4 &q = sph[(size_t)i];
                 strict[j] = q;
-                T.obj[(size_t)(first + j)] = sph_obj[(size_t)i];
-                if (!lift_sphere(q.x, q.y, q.z, q.w, F, (double)kMfmaSlack, slots)) ++outliers;
+                T.obj[(size_t)t * kTileSpheres + j] = sph_obj[(size_t)i];
+                if (lift_sphere(q.x, q.y, q.z, q.w, F, (double)kMfmaSlack, slots)) {
+                    const double g = F.sigma;
+                    const double x = ((double)q.x - F.tx) * g, y = ((double)q.y - F.ty) * g, z = ((double)q.z - F.tz) * g;
+                    cmax = std::max(cmax, std::sqrt(x * x + y * y + z * z));
+                } else {
+                    ++outliers;
+                }
             } else {
                 strict[j] = make_float4(0.0f, 0.0f, 0.0f, std::numeric_limits<float>::quiet_NaN());  // never a hit
                 lift_constant(false, slots);
             }
             for (int k = 0; k < kLiftSlots; ++k) lifted[lift_index(j / 64, j % 64, k)] = slots[k];
         }
-        // Origin limit in the tile's frame: the hard range limit of the lifted form.  The slack that grows with the
-        // distance of the origin only adds candidates; it is no reason to leave the matrix cores.
+        // Range limit in the tile's frame: the hard limit of the lifted form.  The slack that grows with distance only
+        // adds candidates; it is no reason to leave the matrix cores.
         T.frames[(size_t)2 * t] = make_float4(F.tx, F.ty, F.tz, F.sigma);
-        T.frames[(size_t)2 * t + 1] = make_float4(57000.0f, (float)count, 0.0f, 0.0f);
+        T.frames[(size_t)2 * t + 1] = make_float4(57000.0f, (float)count, std::nextafterf((float)cmax, 1e30f), 0.0f);
     }
     T.ok = outliers <= std::max(2, nsph / 16);  // else pass B would do most of the work
     return T;
@@ -909,13 +961,13 @@ RT_API int rt_selftest_filter(rt_ctx *ctx, uint32_t seed, int blocks, int pairs_
     return RT_OK;
 }
 
-RT_API int rt_selftest_matrix_filter(rt_ctx *ctx, uint32_t seed, int blocks, int rounds, int slack_log2, uint64_t out[6]) {
+static int selftest_matrix(rt_ctx *ctx, uint32_t seed, int blocks, int rounds, int slack_log2, int far, uint64_t out[6]) {
     if (!ctx || !out || blocks <= 0 || rounds <= 0 || slack_log2 > -8 || slack_log2 < -30) return RT_ERR_INVALID;
     Bind bind(ctx);
     unsigned long long *dev = nullptr;
     RT_HIP(hipMalloc((void **)&dev, 256));
     hipError_t e = hipMemsetAsync(dev, 0, 256, ctx->stream);
-    if (e == hipSuccess) e = launch_matrix_selftest(seed, blocks, rounds, std::ldexp(1.0f, slack_log2), dev, ctx->stream);
+    if (e == hipSuccess) e = launch_matrix_selftest(seed, blocks, rounds, std::ldexp(1.0f, slack_log2), far, dev, ctx->stream);
     unsigned long long host[6] = {0, 0, 0, 0, 0, 0};
     if (e == hipSuccess) e = hipMemcpyAsync(host, dev, sizeof host, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -923,6 +975,14 @@ RT_API int rt_selftest_matrix_filter(rt_ctx *ctx, uint32_t seed, int blocks, int
     if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_selftest_matrix_filter", e);
     for (int i = 0; i < 6; ++i) out[i] = host[i];
     return RT_OK;
+}
+
+RT_API int rt_selftest_matrix_filter(rt_ctx *ctx, uint32_t seed, int blocks, int rounds, int slack_log2, uint64_t out[6]) {
+    return selftest_matrix(ctx, seed, blocks, rounds, slack_log2, 0, out);
+}
+
+RT_API int rt_selftest_tiled_filter(rt_ctx *ctx, uint32_t seed, int blocks, int rounds, int slack_log2, uint64_t out[6]) {
+    return selftest_matrix(ctx, seed, blocks, rounds, slack_log2, 1, out);
 }
 
 RT_API int rt_trace_times(rt_ctx *ctx, float *ms, int cap, int *count) {

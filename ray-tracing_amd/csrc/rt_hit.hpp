@@ -33,9 +33,9 @@ struct Rec4 { f4v r0, r1, r2, r3; };
 // load1(slot) -- the strict record (center, radius) of one sphere for pass B and the hit record.
 // kFetchMatrix is the staged kind with the matrix-core filter in place of the compact vector filter: strict
 // records and the lifted A operands (rt_lift.hpp) are staged in LDS.
-// kFetchTiled is the matrix-core filter for scenes beyond that: the spheres are sorted along a space-filling curve
-// and cut into tiles of 512, each lifted in a frame of its own; a workgroup streams the tiles through two LDS
-// buffers (asynchronous global -> LDS copies), all its waves working on the same tile between two barriers.
+// kFetchTiled is the matrix-core filter for scenes beyond that: the spheres are partitioned in space into tiles of
+// at most 512, each lifted in a frame of its own; a workgroup streams the tiles through two LDS buffers
+// (asynchronous global -> LDS copies), all its waves working on the same tile between two barriers.
 enum { kFetchLds = 0, kFetchScalar = 1, kFetchStream = 2, kFetchMatrix = 3, kFetchTiled = 4 };
 constexpr int kTileRecords = 128;  // kFetchStream: records per LDS tile (two tiles per wave)
 
@@ -346,19 +346,9 @@ RT_DEV void swap_halves(h8 &x0, h8 &x1) {
     x1 = __builtin_bit_cast(h8, b);
 }
 
-// Ray side of the lifted form, every lane for its own ray, then the exchange that turns the per-lane slot vectors
-// into the four B operands.  oo is |o'|^2 in the scaled frame (the caller compares it with the scene's limit).
-RT_DEV void lift_ray(const LiftFrame &F, V3 o, V3 dn, float slack, float &oo, RayLifted &L) {
-    const float ox = (o.x - F.tx) * F.sigma, oy = (o.y - F.ty) * F.sigma, oz = (o.z - F.tz) * F.sigma;
-    oo = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
-    const float odn = __builtin_fmaf(oz, dn.z, __builtin_fmaf(oy, dn.y, ox * dn.x));
-    float v[10];
-    v[0] = __builtin_fmaf(odn, odn, -(oo * (1.0f - slack)));
-    v[1] = 2.0f * __builtin_fmaf(-odn, dn.x, ox);
-    v[2] = 2.0f * __builtin_fmaf(-odn, dn.y, oy);
-    v[3] = 2.0f * __builtin_fmaf(-odn, dn.z, oz);
-    v[4] = dn.x * dn.x; v[5] = dn.y * dn.y; v[6] = dn.z * dn.z;
-    v[7] = dn.x * dn.y; v[8] = dn.x * dn.z; v[9] = dn.y * dn.z;
+// The ten ray-side values -> FP16 pairs in slot order -> the four B operands (the two halves of the wave exchange
+// their slot vectors).
+RT_DEV void pack_lifted(float (&v)[10], RayLifted &L) {
     // The FP16 pairs must satisfy hi + lo = v to 2^-22: pin each v as a binary32 value so that both uses of its
     // conversion round the same number (otherwise the compiler converts one of them straight from the unrounded
     // fused product, and the two halves of the pair can then disagree by a whole FP16 ulp).
@@ -383,6 +373,57 @@ RT_DEV void lift_ray(const LiftFrame &F, V3 o, V3 dn, float slack, float &oo, Ra
     swap_halves(x10, x11);  // -> K half 1
     L.b00 = x00; L.b10 = x01;
     L.b01 = x10; L.b11 = x11;
+}
+
+// Ray side of the lifted form, every lane for its own ray, then the exchange that turns the per-lane slot vectors
+// into the four B operands.  oo is |o'|^2 in the scaled frame (the caller compares it with the scene's limit).
+RT_DEV void lift_ray(const LiftFrame &F, V3 o, V3 dn, float slack, float &oo, RayLifted &L) {
+    const float ox = (o.x - F.tx) * F.sigma, oy = (o.y - F.ty) * F.sigma, oz = (o.z - F.tz) * F.sigma;
+    oo = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
+    const float odn = __builtin_fmaf(oz, dn.z, __builtin_fmaf(oy, dn.y, ox * dn.x));
+    float v[10];
+    v[0] = __builtin_fmaf(odn, odn, -(oo * (1.0f - slack)));
+    v[1] = 2.0f * __builtin_fmaf(-odn, dn.x, ox);
+    v[2] = 2.0f * __builtin_fmaf(-odn, dn.y, oy);
+    v[3] = 2.0f * __builtin_fmaf(-odn, dn.z, oz);
+    v[4] = dn.x * dn.x; v[5] = dn.y * dn.y; v[6] = dn.z * dn.z;
+    v[7] = dn.x * dn.y; v[8] = dn.x * dn.z; v[9] = dn.y * dn.z;
+    pack_lifted(v, L);
+}
+
+// The same for a frame that is local to a tile of spheres while the ray may start far away (tiled kind).  The
+// filter tests the ray's LINE, so any point of it can stand in for the origin: p = o' - (o'.dn) dn, the point next
+// to the frame's centre, is used, and the relative slack k (|p|^2 + |c'|^2 + r^2) then grows with the distance
+// between line and tile centre instead of with the distance of the ray's origin.  Two things still grow with that
+// distance, and `extra`, added to the ray's constant term, covers them (A = |o'| + cmax >= |o - c| for every sphere
+// of the tile, cmax >= |c'|, u = 2^-24):
+//   the reference's own rounding: its discriminant can be >= 0 while the line misses by 17u |o - c|^2 (see
+//     closest_sphere) -- no conservative filter can do with less; covered by kNearSlack A^2 = 32u A^2;
+//   the displacement of the computed line near the tile: <= 1.75u (|o'| + |p|) from the roundings of o - T and of
+//     p's fused update (an error in the dot product only moves p along the line), <= 1.75u |o'| from the rounding
+//     of the direction, together <= 5.25u |o'|, which moves q by at most 2 |p - c'| times that = 10.5u |o'|
+//     (|p| + cmax); covered by 32u A (|p| + cmax).
+// At 140 units from a tile of r = 0.1 spheres that is r_eff = 0.22 where the origin-based slack gave 0.55.
+// oo returns |p|^2 for the range check; a ray whose constant term leaves the FP16 range reports oo = inf.
+constexpr float kNearSlack = 0x1p-19f;  // 32u
+RT_DEV void lift_ray_near(const LiftFrame &F, float cmax, V3 o, V3 dn, float slack, float near_slack, float &oo, RayLifted &L) {
+    const float fx = (o.x - F.tx) * F.sigma, fy = (o.y - F.ty) * F.sigma, fz = (o.z - F.tz) * F.sigma;
+    const float far2 = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
+    const float t0 = __builtin_fmaf(fz, dn.z, __builtin_fmaf(fy, dn.y, fx * dn.x));
+    const float ox = __builtin_fmaf(-t0, dn.x, fx), oy = __builtin_fmaf(-t0, dn.y, fy), oz = __builtin_fmaf(-t0, dn.z, fz);
+    const float pp = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
+    const float odn = __builtin_fmaf(oz, dn.z, __builtin_fmaf(oy, dn.y, ox * dn.x));
+    const float A = __builtin_sqrtf(far2) * (1.0f + 0x1p-20f) + cmax;
+    const float extra = near_slack * A * (A + __builtin_sqrtf(pp) * (1.0f + 0x1p-20f) + cmax);
+    float v[10];
+    v[0] = __builtin_fmaf(odn, odn, -(pp * (1.0f - slack))) + extra;
+    v[1] = 2.0f * __builtin_fmaf(-odn, dn.x, ox);
+    v[2] = 2.0f * __builtin_fmaf(-odn, dn.y, oy);
+    v[3] = 2.0f * __builtin_fmaf(-odn, dn.z, oz);
+    v[4] = dn.x * dn.x; v[5] = dn.y * dn.y; v[6] = dn.z * dn.z;
+    v[7] = dn.x * dn.y; v[8] = dn.x * dn.z; v[9] = dn.y * dn.z;
+    oo = __builtin_fabsf(v[0]) <= 57000.0f ? pp : __builtin_inff();   // NaN compares false: inf
+    pack_lifted(v, L);
 }
 
 // Pass A on the matrix cores over 64-sphere blocks [blk0, blk1): same candidate words as filter_round.
@@ -528,14 +569,19 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
     return ibest;
 }
 
-// Asynchronous copy of tile t into LDS buffer b: every wave of the workgroup copies 1 KiB pieces, each lane 16 bytes
-// (global_load_lds_dwordx4: per-lane global address, LDS address = wave-uniform base + 16 * lane).
-RT_DEV void tile_copy(const TraceParams &P, const Fetch<kFetchTiled> &f, int t, int b) {
+// Asynchronous copy of tile t (count spheres) into LDS buffer b: every wave of the workgroup copies 1 KiB pieces,
+// each lane 16 bytes (global_load_lds_dwordx4: per-lane global address, LDS address = wave-uniform base + 16 * lane),
+// of the lifted records of the tile's 64-sphere blocks and of its strict records.
+RT_DEV void tile_copy(const TraceParams &P, const Fetch<kFetchTiled> &f, int t, int b, int count) {
     const float4 *src = P.tiles + (size_t)t * kTileVec4 + (threadIdx.x & 63);
     f4v *dst = f.buf + b * kTileVec4;
-    for (int u = (threadIdx.x >> 6) * 64; u < kTileVec4; u += (blockDim.x >> 6) * 64)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + u),
-                                         (__attribute__((address_space(3))) void *)(dst + u), 16, 0, 0);
+    const int blocks = (count + 63) / 64;
+    const int nl = blocks * 256, ns = blocks * 64;  // both multiples of a wave's 64 pieces
+    for (int u = (threadIdx.x >> 6) * 64; u < nl + ns; u += (blockDim.x >> 6) * 64) {
+        const int v = u < nl ? u : kTileLifted + (u - nl);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + v),
+                                         (__attribute__((address_space(3))) void *)(dst + v), 16, 0, 0);
+    }
 }
 
 // closest_sphere for the tiled kind.  Must be called by every wave of the workgroup the same number of times (it
@@ -556,19 +602,19 @@ RT_DEV int closest_sphere_tiled(const TraceParams &P, Fetch<kFetchTiled> &f, uin
     const int lane = threadIdx.x & 63;
     int ibest = -1;
     float nskip = __builtin_inff();
-    tile_copy(P, f, 0, 0);
+    // scalar loads: a vector load in the loop would make the wave wait for the copy it has just started
+    const const_f4_ptr frames = (const_f4_ptr)(uintptr_t)P.tile_frames;
+    tile_copy(P, f, 0, 0, (int)frames[1].y);
     for (int t = 0; t < P.ntiles; ++t) {
         __syncthreads();  // waits for this thread's copies first (the compiler drains vmcnt before the barrier)
-        if (t + 1 < P.ntiles) tile_copy(P, f, t + 1, (t + 1) & 1);
+        if (t + 1 < P.ntiles) tile_copy(P, f, t + 1, (t + 1) & 1, (int)frames[2 * t + 3].y);
         const f4v *tile = f.buf + (t & 1) * kTileVec4;
-        // scalar loads: a vector load here would make the wave wait for the copy it has just started
-        const const_f4_ptr frames = (const_f4_ptr)(uintptr_t)P.tile_frames;
         const f4v fa = frames[2 * t], fb = frames[2 * t + 1];
         const LiftFrame F = {fa.x, fa.y, fa.z, fa.w};
         const int count = (int)fb.y;
         float oo;
         RayLifted lifted;
-        lift_ray(F, o, dn, kMfmaSlack, oo, lifted);
+        lift_ray_near(F, fb.z, o, dn, kMfmaSlack, kNearSlack, oo, lifted);
         const bool general = __builtin_amdgcn_ballot_w64(active && !(oo <= fb.x)) != 0;  // wave-uniform
         uint32_t nz;
         if (general) {

@@ -37,9 +37,11 @@ struct TraceParams {
                             // matrix-core filter the origin is measured in the lifted frame
     const void *sphm;       // matrix-core filter: lifted A operands, 4 KiB per 64-sphere block (rt_lift.hpp)
     LiftFrame lift;         // translation and scale of the lifted frame
-    const float4 *tiles;    // tiled matrix-core kind: per tile of 512 sphere slots, 2048 float4 of lifted A operands in
-                            // the tile's own frame, then the 512 strict records; slots are in tile (spatial) order
-    const float4 *tile_frames;  // per tile (tx, ty, tz, sigma), (origin limit in the tile's frame, spheres, 0, 0)
+    const float4 *tiles;    // tiled matrix-core kind: per tile of 512 sphere slots (up to 512 spheres that lie close
+                            // together), 2048 float4 of lifted A operands in the tile's own frame, then the 512
+                            // strict records
+    const float4 *tile_frames;  // per tile (tx, ty, tz, sigma), (range limit in the tile's frame, spheres,
+                                // largest |c'| of a filtered sphere, 0)
     const int *tile_obj;    // [ntiles * 512] object index of each slot in tile order (-1: padding)
     int ntiles;
     int stage_mats;         // matrix-core kind: sph_obj and mats are staged in LDS too (the launch reserved the room)
@@ -90,7 +92,7 @@ hipError_t run_wavefront(const TraceParams &P, int fetch_kind, int extend_thread
 hipError_t launch_first_hit(const TraceParams &P, float4 *out4, int *ids, hipStream_t stream);
 hipError_t launch_filter_selftest(uint32_t seed, int blocks, int pairs_per_thread, unsigned long long *out,
                                   hipStream_t stream);
-hipError_t launch_matrix_selftest(uint32_t seed, int blocks, int rounds, float slack, unsigned long long *out,
+hipError_t launch_matrix_selftest(uint32_t seed, int blocks, int rounds, float slack, int far, unsigned long long *out,
                                   hipStream_t stream);
 hipError_t launch_fold(float4 *accum, const float4 *planes, int nplanes, int width, int height, int tileX, int tileY,
                        int tileW, int tileH, hipStream_t stream);

@@ -465,6 +465,23 @@ def test_matrix_filter_never_misses_a_reference_candidate(rt, renderer):
     assert a == b
 
 
+def test_tiled_filter_never_misses_a_reference_candidate(rt, renderer):
+    """The form the tiled kind lifts its rays in -- frame local to the spheres, ray origins up to 2^20 radii away,
+    the ray stood on its point next to the frame's centre, a slack term for what still grows with distance (the
+    reference's own rounding and the displacement of the computed line).  No miss at the slack the library renders
+    with, nor at half of it; the margin is thinner than the staged form's by design, because at these distances the
+    reference's rounding error is the larger part of the slack."""
+    for seed, slack in ((1, -16), (2, -16), (3, -16), (4, -17)):
+        r = renderer.selftestTiledFilter(seed=seed, blocks=1024, rounds=48, slack_log2=slack)
+        assert r["pairs"] > 1024 * 4 * 48 * 64 * 64 // 4
+        assert r["reference"] > r["pairs"] // 200
+        assert r["missed"] == 0, r
+        assert r["unflagged"] == 0
+    a = renderer.selftestTiledFilter(seed=1, blocks=1024, rounds=48, slack_log2=-16)
+    b = renderer.selftestTiledFilter(seed=1, blocks=1024, rounds=48, slack_log2=-16)
+    assert a == b
+
+
 @pytest.mark.parametrize("name,kw,w,h,spp,depth,shift", [
     ("three_spheres", {}, 160, 90, 8, 50, 0.0),                       # one block, ground sphere outside the FP16 range
     ("nested_glass", {}, 96, 54, 4, 100, 0.0),                        # concentric shells, 100-bounce paths

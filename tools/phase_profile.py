@@ -5,7 +5,7 @@ import __graft_entry__ as ge
 rt = ge.load_package()
 r = rt.MetalRenderer(0)
 cases = [("cover", {}, 1200, 675, 64, 50), ("nested_glass", {}, 640, 360, 16, 100),
-         ("random_spheres", {"n": 20000}, 640, 360, 8, 50)]
+         ("random_spheres", {"n": int(os.environ.get("NSPH", "20000"))}, 640, 360, 8, 50)]
 if os.environ.get("SIZE"):
     w_, h_, spp_ = (int(v) for v in os.environ["SIZE"].split("x"))
     cases = [(c[0], c[1], w_, h_, spp_, c[5]) for c in cases]
@@ -16,6 +16,7 @@ for name, kw, w, h, spp, depth in cases:
     objs, n = rt.scene(name, **kw)
     r.setupTexture(w, h)
     r.setScene(objs, n)
+    r.set_option(rt.RT_OPT_SCENE_FETCH, int(os.environ.get('FETCH', '0')))
     r.set_option(rt.RT_OPT_CHUNK, int(os.environ.get('CHUNK', '-1')))
     r.set_option(rt.RT_OPT_TAIL_CHUNK, int(os.environ.get('TAIL', '-1')))
     u = rt.config_uniforms(name, w, h, spp, depth, n)
