@@ -398,14 +398,15 @@ RT_DEV void lift_ray(const LiftFrame &F, V3 o, V3 dn, float slack, float &oo, Ra
 // distance, and `extra`, added to the ray's constant term, covers them (A = |o'| + cmax >= |o - c| for every sphere
 // of the tile, cmax >= |c'|, u = 2^-24):
 //   the reference's own rounding: its discriminant can be >= 0 while the line misses by 17u |o - c|^2 (see
-//     closest_sphere) -- no conservative filter can do with less; covered by kNearSlack A^2 = 32u A^2;
+//     closest_sphere) -- no conservative filter can do with less; covered by kNearSlack A^2 = 64u A^2;
 //   the displacement of the computed line near the tile: <= 1.75u (|o'| + |p|) from the roundings of o - T and of
 //     p's fused update (an error in the dot product only moves p along the line), <= 1.75u |o'| from the rounding
 //     of the direction, together <= 5.25u |o'|, which moves q by at most 2 |p - c'| times that = 10.5u |o'|
-//     (|p| + cmax); covered by 32u A (|p| + cmax).
-// At 140 units from a tile of r = 0.1 spheres that is r_eff = 0.22 where the origin-based slack gave 0.55.
+//     (|p| + cmax); covered by 64u A (|p| + cmax).
+// At 140 units from a tile of r = 0.1 spheres that is r_eff = 0.30 where the origin-based slack gave 0.55 and no
+// tile-local relative slack at all.
 // oo returns |p|^2 for the range check; a ray whose constant term leaves the FP16 range reports oo = inf.
-constexpr float kNearSlack = 0x1p-19f;  // 32u
+constexpr float kNearSlack = 0x1p-18f;  // 64u
 RT_DEV void lift_ray_near(const LiftFrame &F, float cmax, V3 o, V3 dn, float slack, float near_slack, float &oo, RayLifted &L) {
     const float fx = (o.x - F.tx) * F.sigma, fy = (o.y - F.ty) * F.sigma, fz = (o.z - F.tz) * F.sigma;
     const float far2 = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));

@@ -469,9 +469,10 @@ def test_tiled_filter_never_misses_a_reference_candidate(rt, renderer):
     """The form the tiled kind lifts its rays in -- frame local to the spheres, ray origins up to 2^20 radii away,
     the ray stood on its point next to the frame's centre, a slack term for what still grows with distance (the
     reference's own rounding and the displacement of the computed line).  No miss at the slack the library renders
-    with, nor at half of it; the margin is thinner than the staged form's by design, because at these distances the
-    reference's rounding error is the larger part of the slack."""
-    for seed, slack in ((1, -16), (2, -16), (3, -16), (4, -17)):
+    with, nor at a quarter of it (the first handful in 10^9 pairs appears at an eighth); the margin is thinner than the
+    staged form's by design, because at these distances the reference's rounding error is the larger part of the
+    slack."""
+    for seed, slack in ((1, -16), (2, -16), (3, -17), (4, -18)):
         r = renderer.selftestTiledFilter(seed=seed, blocks=1024, rounds=48, slack_log2=slack)
         assert r["pairs"] > 1024 * 4 * 48 * 64 * 64 // 4
         assert r["reference"] > r["pairs"] // 200
