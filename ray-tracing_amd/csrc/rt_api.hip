@@ -44,7 +44,7 @@ struct rt_ctx {
     DevBuf<float4> tiles, tile_frames;  // tiled matrix-core kind (TraceParams::tiles)
     DevBuf<int> tile_obj;
     int ntiles = 0;
-    bool tiles_ok = false;     // every tile's frame covers its spheres and leaves room for ray origins
+    bool tiles_ok = false;     // all but a few spheres can be filtered in their tile (the others go to the exact test for every ray)
     LiftFrame lift = {0.0f, 0.0f, 0.0f, 1.0f};
     float oo_limit_m = -1.0f;  // origin limit of the matrix-core filter in the lifted frame; < 0: scene not eligible
     int matrix_outliers = 0;   // spheres the matrix-core filter always passes on to the exact test
