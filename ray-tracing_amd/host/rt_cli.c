@@ -1,7 +1,7 @@
 /*
  * rt_cli.c -- command-line driver: renders one of the named scenes on one GPU and writes a PPM.
  *   rt_render [--scene cover|three_spheres|cornell|nested_glass|random_spheres] [--width W] [--height H]
- *             [--spp N] [--depth D] [--progressive PASSES] [--chunk C] [--fetch 0|1] [--stamps] [--out file.ppm]
+ *             [--spp N] [--depth D] [--progressive PASSES] [--chunk C] [--fetch 0..3] [--filter 0..3] [--wavefront] [--stamps] [--out file.ppm]
  * --progressive runs the reference's tile-by-tile loop (PASSES passes of --spp samples each);
  * otherwise the whole image is traced in one batch call.
  */

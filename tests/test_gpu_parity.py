@@ -678,3 +678,31 @@ def test_wavefront_kernels_bit_exact(rt, oracle, renderer, name, w, h, spp, dept
     stats = [0] * 5
     oracle.image(u, objs, w, h, stats=stats)
     assert st.segments == stats[0]
+
+
+def test_plain_c_host_driver_end_to_end(rt, oracle, tmp_path):
+    """The command-line driver (plain C over the C-ABI, no Python or torch in the process): batch render and the
+    reference's progressive tile flow, each written as a PPM that must equal, byte for byte, the PPM of the oracle's
+    image of the same configuration."""
+    exe = os.path.join(os.path.dirname(HERE), "ray-tracing_amd", "lib", "rt_render")
+    assert os.path.exists(exe), "make builds ray-tracing_amd/lib/rt_render"
+    import subprocess
+    w, h, spp = 64, 36, 6
+    objs, n = rt.scene("three_spheres")
+    u = rt.config_uniforms("three_spheres", w, h, spp, 50, n)
+    want = str(tmp_path / "want.ppm")
+    img = np.ascontiguousarray(oracle.image(u, objs, w, h))
+    assert rt.host_lib().rt_write_ppm(want.encode(), img.ctypes.data, w, h) == 0
+    got = str(tmp_path / "got.ppm")
+    base = [exe, "--scene", "three_spheres", "--width", str(w), "--height", str(h), "--spp", str(spp), "--out", got]
+    subprocess.run(base + ["--chunk", "0"], check=True, timeout=120, stdout=subprocess.DEVNULL)
+    assert open(got, "rb").read() == open(want, "rb").read()
+    # progressive: 2 passes of spp samples through 64x64 tiles = the oracle's two dispatches onto one texture
+    tex = oracle.image(u, objs, w, h)
+    u2 = rt.Uniforms.from_buffer_copy(u)
+    u2.currentSample = 1
+    tex = oracle.image(u2, objs, w, h, tex=tex)
+    assert rt.host_lib().rt_write_ppm(want.encode(), np.ascontiguousarray(tex).ctypes.data, w, h) == 0
+    subprocess.run(base + ["--progressive", "2"], check=True, timeout=120, stdout=subprocess.DEVNULL)
+    assert open(got, "rb").read() == open(want, "rb").read()
+
