@@ -450,6 +450,27 @@ RT_DEV void matrix_group(const h8 a_lo, const h8 a_hi, const RayLifted &L, f32x1
 #endif
 }
 
+// SPARSE: for scenes of thousands of spheres, where a ray has a candidate in few of the blocks.  Writing the sign bits
+// of a 32-sphere group into the words costs 32 half-rate instructions; finding out whether any of the wave's 64 rays
+// has a candidate in the group at all costs 31 full-rate ones and a vote, after which the 32 are skipped when nobody
+// has.  That pays once more than about two thirds of the groups are skipped.
+RT_DEV bool group_has_candidate(const f32x16 &q0, const f32x16 &q1) {
+    // the AND of the 32 bit patterns keeps the sign bit only if every result has it; four independent chains of
+    // v_and_b32 (a full-rate instruction; v_max3_f32 was measured at about 7 clocks, twice v_max_f32)
+    uint32_t m[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const f32x16 &q = c < 2 ? q0 : q1;
+        const int o = (c & 1) * 8;
+        m[c] = __float_as_uint(q[o]);
+#pragma unroll
+        for (int k = 1; k < 8; ++k) m[c] &= __float_as_uint(q[o + k]);
+    }
+    const uint32_t all = (m[0] & m[1]) & (m[2] & m[3]);
+    return __builtin_amdgcn_ballot_w64((int)all >= 0) != 0;  // some lane holds a result without the sign bit
+}
+
+template <bool SPARSE = false>
 RT_DEV uint32_t filter_round_matrix(const h8 *pm, int blk0, int blk1, uint32_t *masks, int lane, const RayLifted &L) {
     uint32_t nz = 0;
     const h8 *A = pm + (size_t)blk0 * 256 + lane;
@@ -460,11 +481,21 @@ RT_DEV uint32_t filter_round_matrix(const h8 *pm, int blk0, int blk1, uint32_t *
         matrix_group(a_lo, a_hi, L, q0, q1);
         a_lo = A[128];  // issued behind the group's barrier: the operands of one group at a time hold registers
         a_hi = A[192];
+        if (!SPARSE || group_has_candidate(q0, q1)) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { w0 = push_sign(w0, q0[k]); w1 = push_sign(w1, q1[k]); }
+            for (int k = 0; k < 16; ++k) { w0 = push_sign(w0, q0[k]); w1 = push_sign(w1, q1[k]); }
+        } else {
+            w0 = 0xFFFFu;
+            w1 = 0xFFFFu;
+        }
         matrix_group(a_lo, a_hi, L, q0, q1);
+        if (!SPARSE || group_has_candidate(q0, q1)) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { w0 = push_sign(w0, q0[k]); w1 = push_sign(w1, q1[k]); }
+            for (int k = 0; k < 16; ++k) { w0 = push_sign(w0, q0[k]); w1 = push_sign(w1, q1[k]); }
+        } else {
+            w0 = (w0 << 16) | 0xFFFFu;
+            w1 = (w1 << 16) | 0xFFFFu;
+        }
         swap_halves(w0, w1);
         const uint32_t c0 = ~w0, c1 = ~w1;
         masks[w * 64 + lane] = c0;
@@ -624,7 +655,10 @@ RT_DEV int closest_sphere_tiled(const TraceParams &P, Fetch<kFetchTiled> &f, uin
             nz = filter_round(ts, 0, (count + 3) / 4, count, wave_masks, lane, y);
         } else {
             __builtin_amdgcn_s_setprio(0);
-            nz = filter_round_matrix((const h8 *)tile, 0, (count + 63) / 64, wave_masks, lane, lifted);
+            if (P.ntiles >= 8)
+                nz = filter_round_matrix<true>((const h8 *)tile, 0, (count + 63) / 64, wave_masks, lane, lifted);
+            else
+                nz = filter_round_matrix<false>((const h8 *)tile, 0, (count + 63) / 64, wave_masks, lane, lifted);
             __builtin_amdgcn_s_setprio(1);
         }
         if (!a_ok || !active) nz = 0;
