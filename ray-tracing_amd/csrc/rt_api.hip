@@ -538,6 +538,7 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
     if (blocks < 1) blocks = 1;
     RT_HIP(hipMemsetAsync(ctx->counters, 0, 256, ctx->stream));
     const int slot = (int)(ctx->launches % rt_ctx::kRing);
+    int path = kind;  // what rt_stats reports
     if (ctx->opt_kernel == 1) {
         // wavefront formulation: a pool of path slots, generate/extend/shade kernels per bounce step
         if (ctx->width > 65535 || ctx->height > 65535)
@@ -548,6 +549,7 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
         RT_HIP(hipEventRecord(ctx->ev0[slot], ctx->stream));
         int steps = 0;
         const int wf_kind = kind == 3 ? 3 : (kind == 0 ? 0 : 1);  // the tiled kind has no wavefront form: scalar cache
+        path = wf_kind;
         RT_HIP(run_wavefront(P, wf_kind, wf_kind == 3 ? threads : 256, ctx->wf_pool.ptr, (int)slots, per_cu * ctx->num_cus,
                              ctx->stream, &steps));
         RT_HIP(hipEventRecord(ctx->ev1[slot], ctx->stream));
@@ -564,7 +566,7 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
     ctx->last = {};
     ctx->last.grid_blocks = (int)blocks;
     ctx->last.block_threads = ctx->opt_kernel == 1 ? 256 : threads;
-    ctx->last.scene_path = kind;
+    ctx->last.scene_path = path;
     return RT_OK;
 }
 
