@@ -5,6 +5,7 @@ relative on t and normal, PSNR >= 45 dB on converged images -- is met with equal
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -705,4 +706,15 @@ def test_plain_c_host_driver_end_to_end(rt, oracle, tmp_path):
     assert rt.host_lib().rt_write_ppm(want.encode(), np.ascontiguousarray(tex).ctypes.data, w, h) == 0
     subprocess.run(base + ["--progressive", "2"], check=True, timeout=120, stdout=subprocess.DEVNULL)
     assert open(got, "rb").read() == open(want, "rb").read()
+
+
+def test_random_scenes_every_fetch_kind_filter_and_kernel_agree():
+    """tools/fuzz_kinds.py on 12 seeds: scenes of 1 to 3500 spheres over three decades of radius and extent, at and far
+    from the origin, flat or cubic, with and without a ground sphere and a duplicated object, rendered through every
+    sphere-fetch kind, filter choice and kernel formulation -- all must give the bits of the scalar-cache vector path
+    (which other tests pin to the oracle)."""
+    import subprocess
+    tool = os.path.join(os.path.dirname(HERE), "tools", "fuzz_kinds.py")
+    out = subprocess.run([sys.executable, tool, "0", "12"], capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
