@@ -28,7 +28,7 @@ oracle:
 	$(MAKE) -C oracle
 
 # instruction-rate and matrix-core probes behind the design (profiles/r01_*.txt are their outputs)
-TOOLS = tools/valu_rate tools/mfma_coexec tools/mfma_f16_probe tools/mfma_split_probe tools/op_rate
+TOOLS = tools/valu_rate tools/mfma_coexec tools/mfma_f16_probe tools/mfma_split_probe tools/op_rate tools/div_probe
 tools: $(TOOLS)
 tools/%: tools/%.hip
 	$(HIPCC) --offload-arch=gfx950 -O3 -ffp-contract=off -o $@ $<

@@ -145,26 +145,59 @@ RT_DEV void apply_normals(Hit &h, V3 dir, V3 outward) {
     h.normal = h.front ? outward : -outward;
 }
 
+// Division of root numerators by a = d.d, the same divisor for every sphere a ray is tested against.  The
+// compiler's correctly rounded n / a is: scale both operands if either needs it (v_div_scale), reciprocal estimate,
+// one refinement of the reciprocal, quotient estimate, two refinements of the quotient (v_div_fmas, v_div_fixup
+// undoing the scaling).  For a in [2^-40, 2^40] and n in [a 2^-12, a 2^90) no operand is scaled and no fix-up
+// applies, so the sequence is the five fused operations of quotient() on a reciprocal that depends on a alone and
+// is refined once per ray.  Same operations, same roundings, same bits (tools/div_probe.hip: 0 differences from
+// n / a on 4.3e9 random pairs over exactly these ranges).  The numerators that reach quotient() are in range:
+// above nmin = a * 0.0009 (up to there the quotient is below kTMin = 0.001, which the interval test rejects, so
+// they are not divided at all), and at most |b| + sqrt(disc) <= 2^65 for a finite discriminant, while a >= 1e-6
+// puts a 2^90 above 2^70 (an infinite numerator never passes the n < nbest test in front of the division).  A wave
+// with a ray whose a is outside [2^-40, 2^40] divides the ordinary way.
+struct RootDiv {
+    float a, r, nmin;
+    bool slow;  // wave-uniform: a ray of this wave has a outside [2^-40, 2^40]; everybody divides the ordinary way
+    RT_DEV float quotient(float n) const {
+        if (slow) return n / a;
+        float q = n * r;
+        float e = __builtin_fmaf(-a, q, n);
+        q = __builtin_fmaf(e, r, q);
+        e = __builtin_fmaf(-a, q, n);
+        return __builtin_fmaf(e, r, q);
+    }
+};
+RT_DEV RootDiv root_div(float a, bool active) {
+    RootDiv d;
+    d.a = a;
+    const float r0 = __builtin_amdgcn_rcpf(a);
+    d.r = __builtin_fmaf(__builtin_fmaf(-a, r0, 1.0f), r0, r0);
+    d.nmin = a * 0.0009f;
+    d.slow = __builtin_amdgcn_ballot_w64(active && !(a >= 0x1p-40f && a <= 0x1p40f)) != 0;
+    return d;
+}
+
 // Root selection of Lib.metal:230-238 against the interval (kTMin, tmax), for a > 0 (callers have excluded
 // |a| < 1e-6, and a = d.d is never negative).  Returns true and the root.
 // nbest is the numerator whose quotient by a is the current tmax (+inf while tmax is still MAXFLOAT).  Division
-// by a positive a is monotonic, so a numerator <= 0 gives a root <= 0 < kTMin and a numerator >= nbest gives a
+// by a positive a is monotonic, so a numerator <= a * 0.0009 gives a root < kTMin and a numerator >= nbest gives a
 // root >= tmax: both fail the reference's strict interval test, and the division is skipped without changing
 // any decision.  On success nbest is updated.
-RT_DEV bool sphere_root(float disc, float b, float a, float tmax, float &nbest, float &root_out) {
+RT_DEV bool sphere_root(float disc, float b, const RootDiv &dv, float tmax, float &nbest, float &root_out) {
     if (disc < 0.0f) return false;
     float sqrtd = __builtin_sqrtf(disc);
     float n = -b - sqrtd;
     bool ok = false;
     float root = 0.0f;
-    if (n > 0.0f && n < nbest) {
-        root = n / a;
+    if (n > dv.nmin && n < nbest) {
+        root = dv.quotient(n);
         ok = kTMin < root && root < tmax;
     }
     if (!ok) {
         n = -b + sqrtd;
-        if (n > 0.0f && n < nbest) {
-            root = n / a;
+        if (n > dv.nmin && n < nbest) {
+            root = dv.quotient(n);
             ok = kTMin < root && root < tmax;
         }
     }
@@ -181,20 +214,20 @@ RT_DEV bool sphere_root(float disc, float b, float a, float tmax, float &nbest, 
 // second.  So roots up to and including tmax are let through here (tie = true when equal), and the caller settles a
 // tie by object index.  nskip is the numerator above which the quotient is certainly greater than tmax: nbest
 // (1 + 2^-22), four ulps, where the correctly rounded quotients by the same a can no longer coincide.
-RT_DEV bool sphere_root_any_order(float disc, float b, float a, float tmax, float nskip, float &n_out, float &root_out, bool &tie) {
+RT_DEV bool sphere_root_any_order(float disc, float b, const RootDiv &dv, float tmax, float nskip, float &n_out, float &root_out, bool &tie) {
     if (disc < 0.0f) return false;
     float sqrtd = __builtin_sqrtf(disc);
     float n = -b - sqrtd;
     bool ok = false;
     float root = 0.0f;
-    if (n > 0.0f && n <= nskip) {
-        root = n / a;
+    if (n > dv.nmin && n <= nskip) {
+        root = dv.quotient(n);
         ok = kTMin < root && root <= tmax;
     }
     if (!ok) {
         n = -b + sqrtd;
-        if (n > 0.0f && n <= nskip) {
-            root = n / a;
+        if (n > dv.nmin && n <= nskip) {
+            root = dv.quotient(n);
             ok = kTMin < root && root <= tmax;
         }
     }

@@ -528,6 +528,7 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
                           Prof<PROF> &prof) {
     const float a = dot(d, d);
     const bool a_ok = !(__builtin_fabsf(a) < 1e-6f);  // Lib.metal:226-228: such a ray hits no sphere
+    const RootDiv dv = root_div(a, active);
     const float s = __builtin_amdgcn_rsqf(a) * kDirScale;
     const V3 dn = v3(d.x * s, d.y * s, d.z * s);
     float oo;
@@ -591,7 +592,7 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
             float c = (ocx * ocx + ocy * ocy + ocz * ocz) - rec.w * rec.w;
             float disc = b * b - a * c;
             float root;
-            if (sphere_root(disc, b, a, tbest, nbest, root)) {
+            if (sphere_root(disc, b, dv, tbest, nbest, root)) {
                 tbest = root;
                 ibest = k;
             }
@@ -629,6 +630,7 @@ RT_DEV int closest_sphere_tiled(const TraceParams &P, Fetch<kFetchTiled> &f, uin
                                 float &tbest, Prof<PROF> &prof) {
     const float a = dot(d, d);
     const bool a_ok = !(__builtin_fabsf(a) < 1e-6f);  // Lib.metal:226-228
+    const RootDiv dv = root_div(a, active);
     const float s = __builtin_amdgcn_rsqf(a) * kDirScale;
     const V3 dn = v3(d.x * s, d.y * s, d.z * s);
     const int lane = threadIdx.x & 63;
@@ -687,7 +689,7 @@ RT_DEV int closest_sphere_tiled(const TraceParams &P, Fetch<kFetchTiled> &f, uin
             float disc = b * b - a * c;
             float root, n;
             bool tie;
-            if (sphere_root_any_order(disc, b, a, tbest, nskip, n, root, tie)) {
+            if (sphere_root_any_order(disc, b, dv, tbest, nskip, n, root, tie)) {
                 const int k = t * kTileSpheres + kl;
                 if (!tie || (ibest >= 0 && P.tile_obj[k] < P.tile_obj[ibest])) {
                     tbest = root;
