@@ -45,8 +45,9 @@ __global__ void probe(uint32_t seed, int iters, unsigned long long *out) {
         // a: mantissa random, exponent -40..40 (mostly near 0); n: exponent of a plus -12..+90
         int ea = (ex & 1) ? (int)((ex >> 1) % 81) - 40 : (int)((ex >> 1) % 5) - 2;
         int en = ea + (int)((ex >> 12) % 103) - 12;
-        float a = __uint_as_float(((uint32_t)(ea + 127) << 23) | (ma >> 9));
-        float n = __uint_as_float(((uint32_t)(en + 127) << 23) | (mn >> 9));
+        // both signs: the quotients of a vector by a (possibly negative) scalar use the same sequence
+        float a = __uint_as_float(((uint32_t)(ea + 127) << 23) | (ma >> 9) | ((ex & 0x400u) << 21));
+        float n = __uint_as_float(((uint32_t)(en + 127) << 23) | (mn >> 9) | ((ex & 0x800u) << 20));
         DivBy d = div_prepare(a);
         float q0 = n / a, q1 = div_fast(n, d);
         ++n_div;
