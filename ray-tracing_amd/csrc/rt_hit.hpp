@@ -15,7 +15,9 @@ namespace rt {
 
 constexpr int kWordGroups = 8;    // groups of 4 spheres per 32-bit candidate word
 constexpr int kRoundWords = 16;   // candidate words per resolve round (512 spheres)
-constexpr int kMaskWordsPerWave = kRoundWords * 64;  // LDS words per wave: one word per lane per round word
+constexpr int kListOffset = kRoundWords * 64;        // after a wave's candidate words: 64 words of candidate list ...
+constexpr int kBestOffset = kListOffset + 64;        // ... and 64 x 64 bits of (distance, slot) minima (resolve_balanced)
+constexpr int kMaskWordsPerWave = kBestOffset + 128; // LDS words per wave
 
 // Filter margins (see closest_sphere).  kDirScale inflates the b side of both filters; the c side is inflated
 // on the host when the records are built: r*r * (1 + 2^-17) in the general records, and a slack of
@@ -505,6 +507,79 @@ RT_DEV uint32_t filter_round_matrix(const h8 *pm, int blk0, int blk1, uint32_t *
     return nz;
 }
 
+// Pass B for slots that are in object order, balanced over the wave.  Lanes differ in how many candidates pass A left
+// them (the cover scene: 1.6 on average, the busiest lane of a wave 2.1), and a loop in which every lane resolves
+// its own runs as long as the busiest lane.  Here the wave's candidates are pooled instead: layer by layer (every
+// lane's first candidate, then every lane's second, ...) they are appended to a list of 64 in LDS; whenever the next
+// layer would not fit, lane j resolves entry j -- it fetches the owner's ray with cross-lane reads, evaluates the
+// reference's arithmetic exactly as the owner would, and offers (distance, slot) to the owner's 64-bit minimum in
+// LDS, distance in the upper half.  Distances are positive floats, whose bit patterns order like unsigned integers,
+// so that minimum is the reference's answer: the smallest accepted root and, among equal roots, the lowest index.
+// (The reference tests a sphere against the best distance so far, Shaders.metal:17-22; a sphere's root that would
+// pass that test is the same root it offers against an unbounded interval, because its second root is never
+// smaller than its first.)
+template <typename F, bool PROF>
+RT_DEV void resolve_balanced(const F &f, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, V3 o, V3 d, const RootDiv &dv,
+                             Prof<PROF> &prof) {
+    uint32_t *list = wave_masks + kListOffset;
+    unsigned long long *best = (unsigned long long *)(wave_masks + kBestOffset);
+    auto flush = [&](int n) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t e = list[lane];
+        const int owner = lane < n ? (int)(e >> 16) : lane, k = (int)(e & 0xFFFFu);
+        // the owner's ray (every lane takes part in the cross-lane reads)
+        const float ox = __shfl(o.x, owner, 64), oy = __shfl(o.y, owner, 64), oz = __shfl(o.z, owner, 64);
+        const float dx = __shfl(d.x, owner, 64), dy = __shfl(d.y, owner, 64), dz = __shfl(d.z, owner, 64);
+        RootDiv q;
+        q.a = __shfl(dv.a, owner, 64);
+        q.r = __shfl(dv.r, owner, 64);
+        q.nmin = q.a * 0.0009f;
+        q.slow = dv.slow;
+        if (lane < n) {
+            if constexpr (PROF) prof.count(7, (uint64_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)));
+            // Lib.metal:216-238 as written
+            f4v rec = f.load1(slot0 + k);  // (center, radius)
+            float ocx = ox - rec.x, ocy = oy - rec.y, ocz = oz - rec.z;
+            float b = ocx * dx + ocy * dy + ocz * dz;
+            float c = (ocx * ocx + ocy * ocy + ocz * ocz) - rec.w * rec.w;
+            float disc = b * b - q.a * c;
+            float root, nbest = __builtin_inff();
+            if (sphere_root(disc, b, q, kMaxFloat, nbest, root))
+                atomicMin(&best[owner], ((unsigned long long)__float_as_uint(root) << 32) | (uint32_t)(slot0 + k));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    uint32_t m = 0;
+    int w = 0, filled = 0;
+    for (;;) {
+        const bool has = m != 0 || nz != 0;
+        const uint64_t layer = __builtin_amdgcn_ballot_w64(has);
+        const int n = __builtin_popcountll(layer);
+        if (filled != 0 && (n == 0 || filled + n > 64)) {
+            prof.count(6);
+            flush(filled);
+            filled = 0;
+        }
+        if (n == 0) break;
+        if (has) {
+            if (m == 0) {
+                w = __builtin_ctz(nz);
+                nz &= nz - 1;
+                m = wave_masks[w * 64 + lane];
+            }
+            const int j = __builtin_clz(m);
+            m &= ~(0x80000000u >> j);
+            const uint32_t pos = (uint32_t)filled + __builtin_amdgcn_mbcnt_hi((uint32_t)(layer >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)layer, 0u));
+            list[pos] = ((uint32_t)lane << 16) | (uint32_t)(w * 32 + j);
+        }
+        filled += n;
+    }
+}
+
 // Closest sphere hit of ray (o, d) over all spheres: the sphere part of world_hit (Shaders.metal:13-32) with
 // hitSphere (Lib.metal:215-246).  Returns the sphere slot or -1; t in tbest.  Must be called by all 64 lanes of the
 // wave (the streaming fetcher loads tiles cooperatively); lanes without a ray pass active = false and get -1.
@@ -540,8 +615,9 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
     }
     const bool general = __builtin_amdgcn_ballot_w64(active && !(oo <= P.oo_limit)) != 0;  // wave-uniform
     const int lane = threadIdx.x & 63;
-    int ibest = -1;
-    float nbest = __builtin_inff();  // numerator of the current closest root, see sphere_root
+    // every lane's closest (distance, slot) so far, kept in LDS where other lanes can lower it (resolve_balanced)
+    unsigned long long *best = (unsigned long long *)(wave_masks + kBestOffset);
+    best[lane] = ((unsigned long long)__float_as_uint(tbest) << 32) | 0xFFFFFFFFull;
     f.start(general);
     for (int g0 = 0; g0 < P.ngroups; g0 += kRoundWords * kWordGroups) {
         const int g1 = min(P.ngroups, g0 + kRoundWords * kWordGroups);
@@ -569,37 +645,12 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
         }
         if (!a_ok || !active) nz = 0;
         prof.lap(1);
-        uint32_t m = 0;
-        int w = 0;
-        for (;;) {
-            if (m == 0) {
-                if (nz == 0) break;
-                w = __builtin_ctz(nz);
-                nz &= nz - 1;
-                m = wave_masks[w * 64 + lane];
-            }
-            const int j = __builtin_clz(m);
-            m &= ~(0x80000000u >> j);
-            if constexpr (PROF) {
-                prof.count(6);
-                prof.count(7, (uint64_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)));
-            }
-            const int k = 4 * g0 + w * 32 + j;
-            // Lib.metal:216-238 as written
-            f4v rec = f.load1(k);  // (center, radius)
-            float ocx = o.x - rec.x, ocy = o.y - rec.y, ocz = o.z - rec.z;
-            float b = ocx * d.x + ocy * d.y + ocz * d.z;
-            float c = (ocx * ocx + ocy * ocy + ocz * ocz) - rec.w * rec.w;
-            float disc = b * b - a * c;
-            float root;
-            if (sphere_root(disc, b, dv, tbest, nbest, root)) {
-                tbest = root;
-                ibest = k;
-            }
-        }
+        resolve_balanced(f, wave_masks, nz, 4 * g0, lane, o, d, dv, prof);
         prof.lap(2);
     }
-    return ibest;
+    const unsigned long long r = best[lane];
+    tbest = __uint_as_float((uint32_t)(r >> 32));
+    return (int)(uint32_t)r;  // 0xFFFFFFFF = -1: no hit
 }
 
 // Asynchronous copy of tile t (count spheres) into LDS buffer b: every wave of the workgroup copies 1 KiB pieces,
