@@ -508,7 +508,7 @@ RT_DEV uint32_t filter_round_matrix(const h8 *pm, int blk0, int blk1, uint32_t *
 }
 
 // Pass B for slots that are in object order, balanced over the wave.  Lanes differ in how many candidates pass A left
-// them (the cover scene: 1.6 on average, the busiest lane of a wave 2.1), and a loop in which every lane resolves
+// them (the cover scene: 2.2 on average, a few lanes of a wave four or five), and a loop in which every lane resolves
 // its own runs as long as the busiest lane.  Here the wave's candidates are pooled instead: layer by layer (every
 // lane's first candidate, then every lane's second, ...) they are appended to a list of 64 in LDS; whenever the next
 // layer would not fit, lane j resolves entry j -- it fetches the owner's ray with cross-lane reads, evaluates the
