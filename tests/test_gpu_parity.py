@@ -681,6 +681,27 @@ def test_wavefront_kernels_bit_exact(rt, oracle, renderer, name, w, h, spp, dept
     assert st.segments == stats[0]
 
 
+def test_staged_matrix_kind_at_its_largest_scene(rt, renderer):
+    """1024 spheres is the most the staged matrix-core kind takes: lifted and strict records plus the per-wave candidate
+    words, list and minima fill the 160 KB of LDS.  Same bits as the scalar-cache vector path."""
+    strict(renderer, rt)
+    objs, n = rt.scene("random_spheres", n=1023, extent=8.0)
+    assert n == 1024
+    u = rt.config_uniforms("random_spheres", 160, 90, 4, 50, n)
+    renderer.setupTexture(160, 90)
+    renderer.setScene(objs, n)
+    imgs = []
+    for fetch, filt, path in ((1, 2, 1), (0, 0, 3)):
+        strict(renderer, rt, fetch=fetch)
+        renderer.set_option(rt.RT_OPT_FILTER, filt)
+        try:
+            imgs.append(renderer.renderImage(u, objs, n).copy())
+            assert renderer.lastStats().scene_path == path
+        finally:
+            strict(renderer, rt)
+    assert np.array_equal(bits(imgs[0]), bits(imgs[1]))
+
+
 def test_plain_c_host_driver_end_to_end(rt, oracle, tmp_path):
     """The command-line driver (plain C over the C-ABI, no Python or torch in the process): batch render and the
     reference's progressive tile flow, each written as a PPM that must equal, byte for byte, the PPM of the oracle's
