@@ -74,14 +74,17 @@ enum {
                                3 = the matrix-core filter for any staged scene it covers, however small */
     RT_OPT_WAVEFRONT_SLOTS = 7, /* path slots of the wavefront pool (default 2^20; 168 bytes of device memory each) */
     RT_OPT_TAIL_CHUNK = 8,  /* the last samples of every pixel are handed out in items of this many samples, after all
-                               longer items, so that the persistent grid drains evenly; 0 = no such tail;
-                               -1 (default) and 0 = no such tail (measured on the cover scene: it costs more in
-                               camera-ray generation than the even drain gains) */
+                               longer items, so that the persistent grid drains evenly; -1 (default) and 0 = no such
+                               tail (measured on the cover scene: it costs more in camera-ray generation than the
+                               even drain gains) */
     RT_OPT_TAIL_SAMPLES = 9 /* samples per pixel in that tail; -1 (default) = automatic */
 };
 
 /* setupMetal (ContentView.swift:328-356): device, queue, pipelines.  `device` is the HIP device ordinal.
- * `stream` is a hipStream_t the library should enqueue on, or NULL to create its own. */
+ * `stream` is a hipStream_t the library should enqueue on, or NULL to create its own (non-blocking) stream.
+ * The legacy default stream has the null handle and therefore cannot be passed.  Whatever else touches the
+ * buffers handed to rt_render / rt_resolve (a collective over the accumulation buffers, say) must run on, or be
+ * ordered against, the context's stream: pass a stream you created and enqueue that work on it. */
 RT_API int rt_create(rt_ctx **out, int device, void *stream);
 RT_API void rt_destroy(rt_ctx *ctx);
 RT_API const char *rt_last_error(const rt_ctx *ctx);
@@ -164,6 +167,10 @@ struct rt_stats {
      * [5] number of main-loop trips, [6] trips of the resolve loop, [7] candidates resolved, summed over lanes
      * (the last three are counts, not cycles). */
     uint64_t phase_cycles[8];
+    /* Executed work of the last launch, counted per wave: wave_trips = closest-hit searches a wave of 64 lanes took
+     * part in (lanes without a ray ride along), matrix_blocks = 64-sphere blocks the waves put through the
+     * matrix-core filter, each 8 v_mfma_f32_32x32x16_f16 (0 for the vector filters). */
+    uint64_t wave_trips, matrix_blocks;
 };
 RT_API int rt_last_stats(rt_ctx *ctx, struct rt_stats *out);
 

@@ -81,7 +81,8 @@ class TileInfo(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("segments", C.c_uint64), ("tests", C.c_uint64), ("samples", C.c_uint64), ("kernel_ms", C.c_float),
                 ("grid_blocks", C.c_int), ("block_threads", C.c_int), ("scene_path", C.c_int),
-                ("chunk", C.c_int), ("chunk_count", C.c_int), ("tail_chunk", C.c_int), ("phase_cycles", C.c_uint64 * 8)]
+                ("chunk", C.c_int), ("chunk_count", C.c_int), ("tail_chunk", C.c_int), ("phase_cycles", C.c_uint64 * 8),
+                ("wave_trips", C.c_uint64), ("matrix_blocks", C.c_uint64)]
 
     def chunk_ranges(self, ray_begin, ray_end):
         """The sample ranges the last rt_render launch summed separately, in the order their sums are added."""
@@ -295,9 +296,16 @@ class MetalRenderer:
     tileSize = 64  # ContentView.swift:279
 
     def __init__(self, device=0, stream=None):
+        """stream: None = the library creates a private non-blocking stream; else a non-zero hipStream_t handle
+        (e.g. ``torch.cuda.Stream().cuda_stream``) that every call enqueues on.  Handle 0, the legacy default
+        stream, is refused: rt_create reads a null handle as "create your own", and work the caller then enqueues on
+        the default stream (a reduce of the accumulation buffer, say) would not be ordered against the library's."""
         self._lib = amd_lib()
         self._ctx = C.c_void_p()
-        rc = self._lib.rt_create(C.byref(self._ctx), device, C.c_void_p(stream) if stream else None)
+        if stream is not None and int(stream) == 0:
+            raise ValueError("stream handle 0 (the default stream) cannot be passed: create a stream of your own, "
+                             "e.g. torch.cuda.Stream(), make it current and pass its handle; or pass None")
+        rc = self._lib.rt_create(C.byref(self._ctx), device, C.c_void_p(int(stream)) if stream is not None else None)
         if rc != 0:
             raise RtError("rt_create failed with code %d (no GPU, or HIP runtime error)" % rc)
         self.objects = []

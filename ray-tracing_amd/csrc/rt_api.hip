@@ -37,6 +37,8 @@ struct rt_ctx {
     DevBuf<float4> target, accum, planes;
     DevBuf<char> wf_pool;
     DevBuf<float4> rayq;  // camera-ray queues of the trace kernel
+    DevBuf<char> staging; // device side of rt_present_bgra8, rt_first_hit and the self-tests; grows, never shrinks
+    uint32_t *wf_host = nullptr;  // pinned host words the wavefront loop reads its queue counters into
 
     // compact scene
     DevBuf<float4> sph, sphc;
@@ -54,6 +56,8 @@ struct rt_ctx {
     int nsph = 0, ngroups = 0, nquad = 0, nobj = 0;
     float oo_limit = -1.0f;
     bool scene_resident = false;
+    std::vector<unsigned char> uploaded;  // bytes of the Object array the device arrays were built from
+    bool uploaded_valid = false;
 
     uint32_t *counters = nullptr;  // 256 B: [0] work counter (u32), [2..3] segment counter (u64)
     static constexpr int kRing = 64;
@@ -300,6 +304,13 @@ TileSet build_tiles(const std::vector<float4> &sph, const std::vector<int> &sph_
 // the slot count is padded to a multiple of 32 with records that can never be hit.
 int upload_scene(rt_ctx *ctx, const Object *objs, int n) {
     if (n < 0 || (n > 0 && !objs)) return fail(ctx, RT_ERR_INVALID, "rt: bad object array");
+    // The reference re-sends its objects with every dispatch (ContentView.swift:689-696), and so may callers of
+    // rt_render_tile: 510 times per pass over a 1080p target.  The bytes are compared with those the device arrays
+    // were built from, and the compaction, lifting, tiling and uploads below are skipped when nothing changed.
+    const size_t nbytes = (size_t)n * sizeof(Object);
+    if (ctx->uploaded_valid && ctx->uploaded.size() == nbytes && (nbytes == 0 || std::memcmp(ctx->uploaded.data(), objs, nbytes) == 0))
+        return RT_OK;
+    ctx->uploaded_valid = false;
     std::vector<float4> sph;
     std::vector<int> sph_obj;
     std::vector<QuadDev> quads;
@@ -444,6 +455,8 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n) {
     ctx->tiles_ok = tileset.ok;
     ctx->nquad = (int)quads.size();
     ctx->nobj = n;
+    ctx->uploaded.assign((const unsigned char *)objs, (const unsigned char *)objs + nbytes);
+    ctx->uploaded_valid = true;
     return RT_OK;
 }
 
@@ -454,8 +467,13 @@ int scene_for_call(rt_ctx *ctx, const Uniforms *u, const Object *objs, int objCo
     if (objs) {
         if (u->objCount < 0 || u->objCount > objCount)
             return fail(ctx, RT_ERR_INVALID, "rt: uniforms.objCount must be within [0, objCount]");
+        const bool same = ctx->uploaded_valid && ctx->uploaded.size() == (size_t)u->objCount * sizeof(Object);
+        const bool was_resident = ctx->scene_resident;
         ctx->scene_resident = false;
-        return upload_scene(ctx, objs, u->objCount);
+        RT_TRY(upload_scene(ctx, objs, u->objCount));
+        // a call that re-sends exactly the resident scene leaves it resident
+        if (same && was_resident && ctx->uploaded_valid) ctx->scene_resident = true;
+        return RT_OK;
     }
     if (!ctx->scene_resident) return fail(ctx, RT_ERR_NO_SCENE, "rt: objs is NULL and no scene was set with rt_set_scene");
     return RT_OK;
@@ -551,7 +569,7 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
         const int wf_kind = kind == 3 ? 3 : (kind == 0 ? 0 : 1);  // the tiled kind has no wavefront form: scalar cache
         path = wf_kind;
         RT_HIP(run_wavefront(P, wf_kind, wf_kind == 3 ? threads : 256, ctx->wf_pool.ptr, (int)slots, per_cu * ctx->num_cus,
-                             ctx->stream, &steps));
+                             ctx->stream, ctx->wf_host, &steps));
         RT_HIP(hipEventRecord(ctx->ev1[slot], ctx->stream));
         blocks = slots / 256;
     } else {
@@ -600,7 +618,8 @@ RT_API int rt_create(rt_ctx **out, int device, void *stream) {
         }
         ctx->own_stream = true;
     }
-    bool ok = hipMalloc((void **)&ctx->counters, 256) == hipSuccess;
+    bool ok = hipMalloc((void **)&ctx->counters, 256) == hipSuccess &&
+              hipHostMalloc((void **)&ctx->wf_host, 64, hipHostMallocDefault) == hipSuccess;
     for (int i = 0; ok && i < rt_ctx::kRing; ++i)
         ok = hipEventCreate(&ctx->ev0[i]) == hipSuccess && hipEventCreate(&ctx->ev1[i]) == hipSuccess;
     if (!ok) {
@@ -623,10 +642,15 @@ RT_API void rt_destroy(rt_ctx *ctx) {
     (void)hipFree(ctx->sph.ptr);
     (void)hipFree(ctx->sphc.ptr);
     (void)hipFree(ctx->sphm.ptr);
+    (void)hipFree(ctx->tiles.ptr);
+    (void)hipFree(ctx->tile_frames.ptr);
+    (void)hipFree(ctx->tile_obj.ptr);
     (void)hipFree(ctx->sph_obj.ptr);
     (void)hipFree(ctx->quads.ptr);
     (void)hipFree(ctx->mats.ptr);
+    (void)hipFree(ctx->staging.ptr);
     (void)hipFree(ctx->counters);
+    if (ctx->wf_host) (void)hipHostFree(ctx->wf_host);
     for (int i = 0; i < rt_ctx::kRing; ++i) {
         if (ctx->ev0[i]) (void)hipEventDestroy(ctx->ev0[i]);
         if (ctx->ev1[i]) (void)hipEventDestroy(ctx->ev1[i]);
@@ -789,13 +813,12 @@ RT_API int rt_present_bgra8(rt_ctx *ctx, uint8_t *out, int out_w, int out_h) {
     if (!ctx || !out || out_w <= 0 || out_h <= 0) return RT_ERR_INVALID;
     if (!ctx->target.ptr) return fail(ctx, RT_ERR_NO_TARGET, "rt: no render target");
     Bind bind(ctx);
-    uint32_t *dev = nullptr;
     size_t bytes = (size_t)out_w * out_h * 4;
-    RT_HIP(hipMalloc((void **)&dev, bytes));
+    RT_TRY(grow(ctx, ctx->staging, bytes));
+    uint32_t *dev = (uint32_t *)ctx->staging.ptr;
     hipError_t e = launch_present_bgra8(ctx->target.ptr, ctx->width, ctx->height, dev, out_w, out_h, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(dev);
     if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_present_bgra8", e);
     return RT_OK;
 }
@@ -913,16 +936,13 @@ RT_API int rt_first_hit(rt_ctx *ctx, const Uniforms *u, const Object *objs, int 
     TraceParams P;
     fill_params(ctx, u, P);
     size_t n = (size_t)ctx->width * ctx->height;
-    float4 *d4 = nullptr;
-    int *dids = nullptr;
-    RT_HIP(hipMalloc((void **)&d4, n * sizeof(float4)));
-    hipError_t e = hipMalloc((void **)&dids, n * sizeof(int));
-    if (e == hipSuccess) e = launch_first_hit(P, d4, dids, ctx->stream);
+    RT_TRY(grow(ctx, ctx->staging, n * (sizeof(float4) + sizeof(int))));
+    float4 *d4 = (float4 *)ctx->staging.ptr;
+    int *dids = (int *)(d4 + n);
+    hipError_t e = launch_first_hit(P, d4, dids, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out4, d4, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(ids, dids, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d4);
-    (void)hipFree(dids);
     if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_first_hit", e);
     return RT_OK;
 }
@@ -943,6 +963,8 @@ RT_API int rt_last_stats(rt_ctx *ctx, rt_stats *out) {
         ctx->last.segments = seg;
         ctx->last.tests = seg * (uint64_t)ctx->nobj;
         for (int i = 0; i < 8; ++i) ctx->last.phase_cycles[i] = (uint64_t)host[4 + 2 * i] | ((uint64_t)host[5 + 2 * i] << 32);
+        ctx->last.wave_trips = (uint64_t)host[20] | ((uint64_t)host[21] << 32);
+        ctx->last.matrix_blocks = (uint64_t)host[22] | ((uint64_t)host[23] << 32);
         ctx->stats_pending = false;
     }
     *out = ctx->last;
@@ -952,14 +974,13 @@ RT_API int rt_last_stats(rt_ctx *ctx, rt_stats *out) {
 RT_API int rt_selftest_filter(rt_ctx *ctx, uint32_t seed, int blocks, int pairs_per_thread, uint64_t out[6]) {
     if (!ctx || !out || blocks <= 0 || pairs_per_thread <= 0) return RT_ERR_INVALID;
     Bind bind(ctx);
-    unsigned long long *dev = nullptr;
-    RT_HIP(hipMalloc((void **)&dev, 256));
+    RT_TRY(grow(ctx, ctx->staging, 256));
+    unsigned long long *dev = (unsigned long long *)ctx->staging.ptr;
     hipError_t e = hipMemsetAsync(dev, 0, 256, ctx->stream);
     if (e == hipSuccess) e = launch_filter_selftest(seed, blocks, pairs_per_thread, dev, ctx->stream);
     unsigned long long host[6] = {0, 0, 0, 0, 0, 0};
     if (e == hipSuccess) e = hipMemcpyAsync(host, dev, sizeof host, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(dev);
     if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_selftest_filter", e);
     for (int i = 0; i < 6; ++i) out[i] = host[i];
     return RT_OK;
@@ -968,14 +989,13 @@ RT_API int rt_selftest_filter(rt_ctx *ctx, uint32_t seed, int blocks, int pairs_
 static int selftest_matrix(rt_ctx *ctx, uint32_t seed, int blocks, int rounds, int slack_log2, int far, uint64_t out[6]) {
     if (!ctx || !out || blocks <= 0 || rounds <= 0 || slack_log2 > -8 || slack_log2 < -30) return RT_ERR_INVALID;
     Bind bind(ctx);
-    unsigned long long *dev = nullptr;
-    RT_HIP(hipMalloc((void **)&dev, 256));
+    RT_TRY(grow(ctx, ctx->staging, 256));
+    unsigned long long *dev = (unsigned long long *)ctx->staging.ptr;
     hipError_t e = hipMemsetAsync(dev, 0, 256, ctx->stream);
     if (e == hipSuccess) e = launch_matrix_selftest(seed, blocks, rounds, std::ldexp(1.0f, slack_log2), far, dev, ctx->stream);
     unsigned long long host[6] = {0, 0, 0, 0, 0, 0};
     if (e == hipSuccess) e = hipMemcpyAsync(host, dev, sizeof host, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(dev);
     if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_selftest_matrix_filter", e);
     for (int i = 0; i < 6; ++i) out[i] = host[i];
     return RT_OK;

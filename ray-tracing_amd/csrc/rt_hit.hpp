@@ -218,6 +218,12 @@ struct Prof {
     RT_DEV void count(int i, uint64_t n = 1) { if constexpr (PROF) t[i] += n; }
 };
 
+// Executed-work counters of one wave, always on (wave-uniform values: scalar registers): closest-hit searches the wave
+// took part in, and 64-sphere blocks it put through the matrix-core filter (8 matrix instructions each).
+struct Work {
+    uint32_t trips = 0, blocks = 0;
+};
+
 // Per-ray constants of the two filters.
 struct RayGeneral { V3 o, dn; };                                          // dn = d * kDirScale / |d|
 struct RayCompact { float ndnx, ndny, ndnz, odn, m2ox, m2oy, m2oz, oo1; };  // -dn, o.dn, -2*o, |o|^2 * (1 - kCompactSlack)
@@ -600,7 +606,7 @@ RT_DEV void resolve_balanced(const F &f, uint32_t *wave_masks, uint32_t nz, int 
 // arithmetic either.
 template <typename F, bool PROF>
 RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool active, V3 o, V3 d, float &tbest,
-                          Prof<PROF> &prof) {
+                          Prof<PROF> &prof, Work &work) {
     const float a = dot(d, d);
     const bool a_ok = !(__builtin_fabsf(a) < 1e-6f);  // Lib.metal:226-228: such a ray hits no sphere
     const RootDiv dv = root_div(a, active);
@@ -631,6 +637,7 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
             __builtin_amdgcn_s_setprio(0);
             nz = filter_round_matrix(f.pm, g0 / 16, (g1 + 15) / 16, wave_masks, lane, lifted);
             __builtin_amdgcn_s_setprio(1);
+            work.blocks += (uint32_t)((g1 + 15) / 16 - g0 / 16);
         } else {
             RayCompact y;
             y.ndnx = -dn.x; y.ndny = -dn.y; y.ndnz = -dn.z;
@@ -678,7 +685,7 @@ RT_DEV void tile_copy(const TraceParams &P, const Fetch<kFetchTiled> &f, int t, 
 // (sphere_root_any_order).  Returns the sphere slot in tile order.
 template <bool PROF>
 RT_DEV int closest_sphere_tiled(const TraceParams &P, Fetch<kFetchTiled> &f, uint32_t *wave_masks, bool active, V3 o, V3 d,
-                                float &tbest, Prof<PROF> &prof) {
+                                float &tbest, Prof<PROF> &prof, Work &work) {
     const float a = dot(d, d);
     const bool a_ok = !(__builtin_fabsf(a) < 1e-6f);  // Lib.metal:226-228
     const RootDiv dv = root_div(a, active);
@@ -691,7 +698,11 @@ RT_DEV int closest_sphere_tiled(const TraceParams &P, Fetch<kFetchTiled> &f, uin
     const const_f4_ptr frames = (const_f4_ptr)(uintptr_t)P.tile_frames;
     tile_copy(P, f, 0, 0, (int)frames[1].y);
     for (int t = 0; t < P.ntiles; ++t) {
-        __syncthreads();  // waits for this thread's copies first (the compiler drains vmcnt before the barrier)
+        // The copy of tile t is this wave's only outstanding vector-memory operation here.  A workgroup barrier orders
+        // LDS traffic (lgkmcnt) but does not wait for global -> LDS copies (vmcnt), and another wave reads the piece
+        // this wave copied right after the barrier: wait for the copy explicitly.
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0), expcnt and lgkmcnt untouched
+        __syncthreads();
         if (t + 1 < P.ntiles) tile_copy(P, f, t + 1, (t + 1) & 1, (int)frames[2 * t + 3].y);
         const f4v *tile = f.buf + (t & 1) * kTileVec4;
         const f4v fa = frames[2 * t], fb = frames[2 * t + 1];
@@ -713,6 +724,7 @@ RT_DEV int closest_sphere_tiled(const TraceParams &P, Fetch<kFetchTiled> &f, uin
             else
                 nz = filter_round_matrix<false>((const h8 *)tile, 0, (count + 63) / 64, wave_masks, lane, lifted);
             __builtin_amdgcn_s_setprio(1);
+            work.blocks += (uint32_t)((count + 63) / 64);
         }
         if (!a_ok || !active) nz = 0;
         prof.lap(1);
@@ -757,13 +769,14 @@ RT_DEV int closest_sphere_tiled(const TraceParams &P, Fetch<kFetchTiled> &f, uin
 // Closest hit over spheres and quads; fills hit and returns the object index or -1.
 template <typename F, bool PROF>
 RT_DEV int world_hit(const TraceParams &P, F &f, uint32_t *wave_masks, bool active, V3 o, V3 d, Hit &hit, float &t_out,
-                     Prof<PROF> &prof) {
+                     Prof<PROF> &prof, Work &work) {
     float tbest = kMaxFloat;
     int slot;
+    ++work.trips;
     if constexpr (F::kTiled) {
-        slot = closest_sphere_tiled(P, f, wave_masks, active, o, d, tbest, prof);
+        slot = closest_sphere_tiled(P, f, wave_masks, active, o, d, tbest, prof, work);
     } else {
-        slot = closest_sphere(P, f, wave_masks, active, o, d, tbest, prof);
+        slot = closest_sphere(P, f, wave_masks, active, o, d, tbest, prof, work);
     }
     int obj = -1;
     if (slot >= 0) {

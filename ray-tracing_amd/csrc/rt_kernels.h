@@ -61,7 +61,9 @@ struct TraceParams {
     uint32_t nitems;        // tileW * tileH * number of chunks
     uint32_t *counter;      // work-item counter, zeroed before the launch
     unsigned long long *seg_counter;  // [0] += number of closest-hit searches; [1..8] += phase cycle stamps and
-                                      // counts of the diagnostic instantiation
+                                      // counts of the diagnostic instantiation; [9] += closest-hit searches counted
+                                      // per wave (idle lanes ride along); [10] += 64-sphere blocks the waves put
+                                      // through the matrix-core filter
     float4 *planes;         // kModeAccum: [nchunks][width*height] partial sums, one plane per chunk
     float4 *target;         // kModeProgressive: rgba32Float render target
     int mode;
@@ -87,8 +89,9 @@ size_t trace_lds_bytes(const TraceParams &P, int fetch_kind, int threads);
 // Wavefront formulation (rt_wavefront.hip): blocks until the launch is complete.
 size_t wavefront_pool_alloc_bytes(int slots);
 // fetch_kind 0, 1 or 3; extend_threads: workgroup size of the extend kernel (256, or what trace_launch_shape gives for 3).
+// host_cnt: at least 32 bytes of pinned host memory for the queue counters read back between bounce steps.
 hipError_t run_wavefront(const TraceParams &P, int fetch_kind, int extend_threads, void *pool, int slots, int extend_blocks,
-                         hipStream_t stream, int *steps_out);
+                         hipStream_t stream, uint32_t *host_cnt, int *steps_out);
 hipError_t launch_first_hit(const TraceParams &P, float4 *out4, int *ids, hipStream_t stream);
 hipError_t launch_filter_selftest(uint32_t seed, int blocks, int pairs_per_thread, unsigned long long *out,
                                   hipStream_t stream);

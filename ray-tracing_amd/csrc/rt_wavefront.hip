@@ -174,6 +174,7 @@ __global__ __launch_bounds__(KIND == kFetchMatrix ? 1024 : 256) void wf_extend_k
     Fetch<KIND> fetch;
     stage_scene<KIND>(P, lds_words, wave_masks, fetch);
     uint64_t nseg = 0;
+    Work work;
     for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
         const uint32_t i = base + threadIdx.x;
         const bool active = i < n;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(KIND == kFetchMatrix ? 1024 : 256) void wf_extend_k
         Hit hit;
         float t;
         Prof<false> prof;
-        int obj = world_hit(P, fetch, wave_masks, active, o, d, hit, t, prof);
+        int obj = world_hit(P, fetch, wave_masks, active, o, d, hit, t, prof, work);
         bool miss = active && obj < 0;
         int kind = -1;
         if (active && obj >= 0) {
@@ -203,6 +204,10 @@ __global__ __launch_bounds__(KIND == kFetchMatrix ? 1024 : 256) void wf_extend_k
     }
     for (int off = 32; off > 0; off >>= 1) nseg += __shfl_down(nseg, off, 64);
     if ((threadIdx.x & 63) == 0 && nseg) atomicAdd(P.seg_counter, (unsigned long long)nseg);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(P.seg_counter + 9, (unsigned long long)work.trips);
+        atomicAdd(P.seg_counter + 10, (unsigned long long)work.blocks);
+    }
 }
 
 __global__ __launch_bounds__(256) void wf_shade_kernel(const TraceParams P, const WfPool W, int next) {
@@ -285,7 +290,7 @@ size_t wavefront_pool_alloc_bytes(int slots) { return wavefront_pool_bytes(slots
 // Runs the whole launch: returns when every item is done (it has to read the queue counter back to know).
 // pool: device memory of wavefront_pool_alloc_bytes(slots) bytes.  steps_out: bounce steps executed.
 hipError_t run_wavefront(const TraceParams &P, int fetch_kind, int extend_threads, void *pool, int slots, int extend_blocks,
-                         hipStream_t stream, int *steps_out) {
+                         hipStream_t stream, uint32_t *host_cnt, int *steps_out) {
     WfPool W = carve_pool(pool, slots);
     const int blocks = (slots + 255) / 256;
     const int ext_need = (slots + extend_threads - 1) / extend_threads;
@@ -293,16 +298,17 @@ hipError_t run_wavefront(const TraceParams &P, int fetch_kind, int extend_thread
     hipError_t e = hipMemsetAsync(W.cnt, 0, 256, stream);
     if (e != hipSuccess) return e;
     const size_t lds = trace_lds_bytes(P, fetch_kind, extend_threads);
-    if (fetch_kind == kFetchMatrix && lds > 64 * 1024) {
-        e = hipFuncSetAttribute((const void *)wf_extend_kernel<kFetchMatrix>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 64 * 1024) {
+        const void *fn = fetch_kind == kFetchMatrix ? (const void *)wf_extend_kernel<kFetchMatrix>
+                         : fetch_kind == kFetchLds  ? (const void *)wf_extend_kernel<kFetchLds>
+                                                    : (const void *)wf_extend_kernel<kFetchScalar>;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     int cur = 0;
     hipLaunchKernelGGL(wf_generate_kernel, dim3(blocks), dim3(256), 0, stream, P, W, cur, 1);
     int steps = 0;
-    uint32_t *host_cnt = nullptr;
-    e = hipHostMalloc((void **)&host_cnt, 64, hipHostMallocDefault);
-    if (e != hipSuccess) return e;
+    if (!host_cnt) return hipErrorInvalidValue;
     for (;;) {
         const int next = cur ^ 1;
         if (fetch_kind == kFetchMatrix)
@@ -325,7 +331,6 @@ hipError_t run_wavefront(const TraceParams &P, int fetch_kind, int extend_thread
         if (steps > (1 << 28)) { e = hipErrorUnknown; break; }
     }
     if (e == hipSuccess) e = hipGetLastError();
-    (void)hipHostFree(host_cnt);
     if (steps_out) *steps_out = steps;
     return e;
 }
