@@ -19,6 +19,7 @@
 #ifndef RT_AMD_H
 #define RT_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #include "rt_abi.h"
@@ -128,6 +129,20 @@ RT_API int rt_set_scene(rt_ctx *ctx, const struct Object *objs, int objCount);
  * Enqueued on the context's stream; returns without waiting. */
 RT_API int rt_render(rt_ctx *ctx, const struct Uniforms *u, const struct Object *objs, int objCount, int ray_begin,
                      int ray_end, float *accum_dev);
+/* No counterpart in the reference.  rt_render for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  Same arguments and results as
+ * rt_render(ctx, u, NULL, 0, ray_begin, ray_end, accum_dev), bit for bit, with two differences: the scene is always
+ * the one kept by rt_set_scene (uploading objects allocates), and the launch's scratch -- work counters, camera-ray
+ * queues, partial-sum planes -- lies in a static device array of RT_NOALLOC_SCRATCH_BYTES that every GPU the library
+ * runs on holds until the process ends, instead of in buffers the context grows on demand.  The call allocates and
+ * frees nothing.  Limits: (number of sample chunks per pixel) x width x height x 16 bytes of the render target must
+ * not exceed RT_NOALLOC_PLANE_BYTES, else RT_ERR_TOO_LARGE (raise RT_OPT_CHUNK, or trace fewer samples per call);
+ * the persistent grid is cut to the 32 768 lanes the queue part holds, so large frames trace slower than with
+ * rt_render; RT_OPT_KERNEL 1 (wavefront) is refused.  All contexts on one GPU share that GPU's array: calls that
+ * overlap on one GPU (two contexts, two streams) race, and rt_last_stats must be read before the next such call. */
+#define RT_NOALLOC_PLANE_BYTES ((size_t)64 << 20)
+#define RT_NOALLOC_SCRATCH_BYTES (256 + ((size_t)64 << 20) + RT_NOALLOC_PLANE_BYTES)
+RT_API int rt_render_noalloc(rt_ctx *ctx, const struct Uniforms *u, int ray_begin, int ray_end, float *accum_dev);
 /* Zero an accumulation buffer (the context's own when NULL).  Enqueued on the stream. */
 RT_API int rt_accum_clear(rt_ctx *ctx, float *accum_dev);
 /* Device address of the context's own accumulation buffer (width*height*4 floats). */

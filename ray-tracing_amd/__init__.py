@@ -100,11 +100,13 @@ class Stats(C.Structure):
 
 RT_OPT_CHUNK, RT_OPT_KERNEL, RT_OPT_SCENE_FETCH, RT_OPT_BLOCKS_PER_CU, RT_OPT_FILTER, RT_OPT_WAVEFRONT_SLOTS = 1, 3, 4, 5, 6, 7
 RT_OPT_TAIL_CHUNK, RT_OPT_TAIL_SAMPLES = 8, 9
+RT_NOALLOC_PLANE_BYTES = 64 << 20  # include/rt_amd.h
 
 # Every symbol include/rt_amd.h declares.
 AMD_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_option", "rt_get_option", "rt_set_target", "rt_clear",
     "rt_write_target", "rt_read_target", "rt_render_tile", "rt_present_bgra8", "rt_set_scene", "rt_render",
+    "rt_render_noalloc",
     "rt_accum_clear", "rt_accum_ptr", "rt_resolve", "rt_synchronize", "rt_first_hit", "rt_last_stats", "rt_trace_times",
     "rt_selftest_filter", "rt_selftest_matrix_filter", "rt_selftest_tiled_filter",
 ]
@@ -140,6 +142,7 @@ def amd_lib():
         lib.rt_present_bgra8.argtypes = [vp, vp, ip, ip]
         lib.rt_set_scene.argtypes = [vp, vp, ip]
         lib.rt_render.argtypes = [vp, C.POINTER(Uniforms), vp, ip, ip, ip, vp]
+        lib.rt_render_noalloc.argtypes = [vp, C.POINTER(Uniforms), ip, ip, vp]
         lib.rt_accum_clear.argtypes = [vp, vp]
         lib.rt_accum_ptr.argtypes = [vp, C.POINTER(vp)]
         lib.rt_resolve.argtypes = [vp, vp, ip]
@@ -425,6 +428,12 @@ class MetalRenderer:
         ray_end = u.sampleCount if ray_end is None else ray_end
         self._check(self._lib.rt_render(self._ctx, C.byref(u), objs, n, ray_begin, ray_end,
                                         C.c_void_p(accum_dev) if accum_dev else None))
+
+    def renderNoAlloc(self, u, ray_begin=0, ray_end=None, accum_dev=None):
+        """rt_render on the resident scene with the library's static device scratch: allocates nothing."""
+        ray_end = u.sampleCount if ray_end is None else ray_end
+        self._check(self._lib.rt_render_noalloc(self._ctx, C.byref(u), ray_begin, ray_end,
+                                                C.c_void_p(accum_dev) if accum_dev else None))
 
     def accumClear(self, accum_dev=None):
         self._check(self._lib.rt_accum_clear(self._ctx, C.c_void_p(accum_dev) if accum_dev else None))

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <functional>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -26,6 +27,22 @@ struct DevBuf {
     size_t cap = 0;  // elements
 };
 }  // namespace
+
+// Scratch of rt_render_noalloc: device memory that belongs to the library itself, so that entry point never has to
+// allocate.  Layout (bytes): [0, 256) work and segment counters, [kScratchQueueOffset, + kScratchQueueBytes) camera-ray
+// queues, [kScratchPlaneOffset, + kScratchPlaneBytes) partial-sum planes.  Every GPU the library runs on holds its own
+// copy of the array, at its own address, until the process ends.  In host code the array's name is only a handle for
+// hipGetSymbolAddress; the address the kernels are given is looked up once per device (scratch_for_device).
+namespace {
+constexpr size_t kScratchQueueOffset = 256;
+constexpr size_t kScratchQueueBytes = (size_t)64 << 20;   // 32 768 lanes x 64 rays x 32 bytes
+static_assert(kScratchQueueBytes % ((size_t)1024 * kQueueRays * 2 * sizeof(float4)) == 0, "whole workgroups of up to 1024 threads");
+constexpr size_t kScratchPlaneOffset = kScratchQueueOffset + kScratchQueueBytes;
+constexpr size_t kScratchPlaneBytes = RT_NOALLOC_PLANE_BYTES;   // chunk planes x width x height x 16 bytes
+constexpr size_t kScratchBytes = kScratchPlaneOffset + kScratchPlaneBytes;
+constexpr int kScratchMaxDevices = 64;
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 
 struct rt_ctx {
     int device = 0;
@@ -60,6 +77,8 @@ struct rt_ctx {
     bool uploaded_valid = false;
 
     uint32_t *counters = nullptr;  // 256 B: [0] work counter (u32), [2..3] segment counter (u64)
+    unsigned char *scratch_dev = nullptr;  // this device's copy of the static scratch array (rt_render_noalloc)
+    uint32_t *stats_src = nullptr;  // counter block the last trace launch wrote (counters, or the head of scratch_dev)
     static constexpr int kRing = 64;
     hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};
     unsigned long long launches = 0;    // trace launches so far
@@ -95,6 +114,24 @@ int fail(rt_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
         }
     }
     return code;
+}
+
+// Device address of the static scratch array on `device`, which must be the current device.  Looked up once per
+// device and kept: each GPU holds its own copy of the array at its own address.
+hipError_t scratch_for_device(int device, unsigned char **out) {
+    static std::mutex lock;
+    static unsigned char *table[kScratchMaxDevices] = {};
+    if (device < 0 || device >= kScratchMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> guard(lock);
+    if (!table[device]) {
+        unsigned char *p = nullptr;
+        hipError_t e = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        table[device] = p;
+    }
+    *out = table[device];
+    return hipSuccess;
 }
 
 #define RT_HIP(call)                                                    \
@@ -515,8 +552,9 @@ void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
     P.target = ctx->target.ptr;
 }
 
-// Enqueue one trace launch (counter reset, events, kernel).
-int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
+// Enqueue one trace launch (counter reset, events, kernel).  noalloc: counters and camera-ray queues come from the
+// device's static scratch array, the grid is cut to what its queues hold, and nothing is allocated.
+int enqueue_trace(rt_ctx *ctx, TraceParams &P, bool noalloc = false) {
     // 0: staged in LDS when the scene fits, else scalar cache (measured faster than streaming on a 100 000-sphere
     // scene: 84 vs 78 TFLOP/s algorithmic); 1: scalar cache; 2: streamed through per-wave LDS tiles
     int kind = ctx->opt_fetch == 2 ? 2 : ((ctx->opt_fetch == 0 || ctx->opt_fetch == 3) && 4 * P.ngroups <= kMaxLdsSpheres) ? 0 : 1;
@@ -554,7 +592,18 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
     long long need = ((long long)P.nitems + threads - 1) / threads;
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
-    RT_HIP(hipMemsetAsync(ctx->counters, 0, 256, ctx->stream));
+    uint32_t *counters = ctx->counters;
+    if (noalloc) {
+        if (ctx->opt_kernel == 1)
+            return fail(ctx, RT_ERR_INVALID, "rt_render_noalloc: the wavefront formulation allocates its path pool; use RT_OPT_KERNEL 0");
+        const long long fit = (long long)(kScratchQueueBytes / ((size_t)threads * kQueueRays * 2 * sizeof(float4)));
+        if (blocks > fit) blocks = fit;  // which lane traces which item does not change any sum
+        counters = (uint32_t *)ctx->scratch_dev;
+        P.counter = counters;
+        P.seg_counter = (unsigned long long *)(counters + 2);
+    }
+    ctx->stats_src = counters;
+    RT_HIP(hipMemsetAsync(counters, 0, 256, ctx->stream));
     const int slot = (int)(ctx->launches % rt_ctx::kRing);
     int path = kind;  // what rt_stats reports
     if (ctx->opt_kernel == 1) {
@@ -573,8 +622,12 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P) {
         RT_HIP(hipEventRecord(ctx->ev1[slot], ctx->stream));
         blocks = slots / 256;
     } else {
-        RT_TRY(grow(ctx, ctx->rayq, (size_t)blocks * threads * kQueueRays * 2));
-        P.rayq = ctx->rayq.ptr;
+        if (noalloc) {
+            P.rayq = (float4 *)(ctx->scratch_dev + kScratchQueueOffset);
+        } else {
+            RT_TRY(grow(ctx, ctx->rayq, (size_t)blocks * threads * kQueueRays * 2));
+            P.rayq = ctx->rayq.ptr;
+        }
         RT_HIP(hipEventRecord(ctx->ev0[slot], ctx->stream));
         RT_HIP(launch_trace(P, kind, ctx->opt_kernel == 2, (int)blocks, threads, ctx->stream));
         RT_HIP(hipEventRecord(ctx->ev1[slot], ctx->stream));
@@ -618,7 +671,8 @@ RT_API int rt_create(rt_ctx **out, int device, void *stream) {
         }
         ctx->own_stream = true;
     }
-    bool ok = hipMalloc((void **)&ctx->counters, 256) == hipSuccess &&
+    bool ok = scratch_for_device(device, &ctx->scratch_dev) == hipSuccess &&
+              hipMalloc((void **)&ctx->counters, 256) == hipSuccess &&
               hipHostMalloc((void **)&ctx->wf_host, 64, hipHostMallocDefault) == hipSuccess;
     for (int i = 0; ok && i < rt_ctx::kRing; ++i)
         ok = hipEventCreate(&ctx->ev0[i]) == hipSuccess && hipEventCreate(&ctx->ev1[i]) == hipSuccess;
@@ -823,8 +877,8 @@ RT_API int rt_present_bgra8(rt_ctx *ctx, uint8_t *out, int out_w, int out_h) {
     return RT_OK;
 }
 
-RT_API int rt_render(rt_ctx *ctx, const Uniforms *u, const Object *objs, int objCount, int ray_begin, int ray_end,
-                     float *accum_dev) {
+static int render_batch(rt_ctx *ctx, const Uniforms *u, const Object *objs, int objCount, int ray_begin, int ray_end,
+                        float *accum_dev, bool noalloc) {
     if (!ctx || !u) return RT_ERR_INVALID;
     if (!ctx->target.ptr) return fail(ctx, RT_ERR_NO_TARGET, "rt: no render target");
     if (ray_begin < 0 || ray_end < ray_begin) return fail(ctx, RT_ERR_INVALID, "rt: bad ray index range");
@@ -833,6 +887,10 @@ RT_API int rt_render(rt_ctx *ctx, const Uniforms *u, const Object *objs, int obj
         return fail(ctx, RT_ERR_INVALID, "rt: tile rectangle must lie inside the render target");
     if (u->currentSample > 10000) return fail(ctx, RT_ERR_INVALID, "rt: currentSample > 10000 (the reference paints yellow)");
     Bind bind(ctx);
+    if (noalloc) {
+        if (objs) return fail(ctx, RT_ERR_INVALID, "rt_render_noalloc: objs must be NULL (uploading a scene allocates); call rt_set_scene first");
+        if (!accum_dev && !ctx->accum.ptr) return fail(ctx, RT_ERR_NO_TARGET, "rt: no render target");
+    }
     RT_TRY(scene_for_call(ctx, u, objs, objCount));
     if (ray_end == ray_begin) return RT_OK;
 
@@ -872,7 +930,22 @@ RT_API int rt_render(rt_ctx *ctx, const Uniforms *u, const Object *objs, int obj
     }
     const unsigned long long nitems = (unsigned long long)pixels * nchunks;
     if (nitems > 0xF0000000ull) return fail(ctx, RT_ERR_TOO_LARGE, "rt: too many work items; raise RT_OPT_CHUNK");
-    RT_TRY(grow(ctx, ctx->planes, (size_t)nchunks * ctx->width * ctx->height));
+    float4 *planes;
+    if (noalloc) {
+        const size_t need = (size_t)nchunks * ctx->width * ctx->height * sizeof(float4);
+        if (need > kScratchPlaneBytes) {
+            char msg[256];
+            std::snprintf(msg, sizeof msg,
+                          "rt_render_noalloc: %d partial-sum planes of %dx%d need %zu bytes, the static scratch holds %zu; "
+                          "raise RT_OPT_CHUNK, trace fewer samples per call, or use rt_render",
+                          nchunks, ctx->width, ctx->height, need, kScratchPlaneBytes);
+            return fail(ctx, RT_ERR_TOO_LARGE, msg);
+        }
+        planes = (float4 *)(ctx->scratch_dev + kScratchPlaneOffset);
+    } else {
+        RT_TRY(grow(ctx, ctx->planes, (size_t)nchunks * ctx->width * ctx->height));
+        planes = ctx->planes.ptr;
+    }
 
     TraceParams P;
     fill_params(ctx, u, P);
@@ -884,16 +957,25 @@ RT_API int rt_render(rt_ctx *ctx, const Uniforms *u, const Object *objs, int obj
     P.chunk_small = small;
     P.nitems = (uint32_t)nitems;
     P.mode = kModeAccum;
-    P.planes = ctx->planes.ptr;
-    RT_TRY(enqueue_trace(ctx, P));
+    P.planes = planes;
+    RT_TRY(enqueue_trace(ctx, P, noalloc));
     ctx->last.samples = (uint64_t)u->tileWidth * u->tileHeight * (uint64_t)nrays;
     ctx->last.chunk = chunk;
     ctx->last.chunk_count = nbig;
     ctx->last.tail_chunk = small;
     float4 *acc = accum_dev ? (float4 *)accum_dev : ctx->accum.ptr;
-    RT_HIP(launch_fold(acc, ctx->planes.ptr, nchunks, ctx->width, ctx->height, P.tileX, P.tileY, P.tileW, P.tileH,
+    RT_HIP(launch_fold(acc, planes, nchunks, ctx->width, ctx->height, P.tileX, P.tileY, P.tileW, P.tileH,
                        ctx->stream));
     return RT_OK;
+}
+
+RT_API int rt_render(rt_ctx *ctx, const Uniforms *u, const Object *objs, int objCount, int ray_begin, int ray_end,
+                     float *accum_dev) {
+    return render_batch(ctx, u, objs, objCount, ray_begin, ray_end, accum_dev, false);
+}
+
+RT_API int rt_render_noalloc(rt_ctx *ctx, const Uniforms *u, int ray_begin, int ray_end, float *accum_dev) {
+    return render_batch(ctx, u, nullptr, 0, ray_begin, ray_end, accum_dev, true);
 }
 
 RT_API int rt_accum_clear(rt_ctx *ctx, float *accum_dev) {
@@ -956,7 +1038,7 @@ RT_API int rt_last_stats(rt_ctx *ctx, rt_stats *out) {
         const int slot = (int)((ctx->launches - 1) % rt_ctx::kRing);
         RT_HIP(hipEventElapsedTime(&ms, ctx->ev0[slot], ctx->ev1[slot]));
         uint32_t host[24] = {0};
-        RT_HIP(hipMemcpyAsync(host, ctx->counters, sizeof host, hipMemcpyDeviceToHost, ctx->stream));
+        RT_HIP(hipMemcpyAsync(host, ctx->stats_src ? ctx->stats_src : ctx->counters, sizeof host, hipMemcpyDeviceToHost, ctx->stream));
         RT_HIP(hipStreamSynchronize(ctx->stream));
         uint64_t seg = (uint64_t)host[2] | ((uint64_t)host[3] << 32);
         ctx->last.kernel_ms = ms;
