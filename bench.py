@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X FP32 vector peak (256 CUs x 256 flop/clk x 2.4 GHz)
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense FP16 matrix peak
 FLOPS_PER_TEST = 23            # one ray-sphere test as the reference writes it, up to the discriminant early-out
-MFMA_FLOPS_PER_PAIR = 64       # matrix-core filter: K = 32 multiply-adds per (sphere slot, ray) pair
+MFMA_FLOPS_PER_BLOCK = 8 * 2 * 32 * 32 * 16  # one 64-sphere block x 64 rays: 8 v_mfma_f32_32x32x16_f16
 
 
 def parse():
@@ -48,32 +48,52 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo is for rehearsing N > 1 on fewer GPUs")
     p.add_argument("--cpu-spp", type=int, default=64, help="spp of the sub-sampled CPU baseline run")
-    p.add_argument("--cpu-stride", type=int, default=4, help="pixel stride of the sub-sampled CPU baseline run")
+    p.add_argument("--cpu-stride", type=int, default=8, help="pixel stride of the sub-sampled CPU baseline run")
+    p.add_argument("--cpu-runs", type=int, default=3, help="repetitions of the CPU baseline run (the best is reported)")
+    p.add_argument("--valu-steps", type=int, default=2, help="N = 1: extra timed steps with the vector sphere filter "
+                   "(the design point the FP32 vector peak applies to); 0 = skip")
+    p.add_argument("--dump", default=None, help="rank 0 writes the last step's reduced linear sums and resolved image "
+                   "to this .npz file")
     return p.parse_args()
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(rt, ge, args):
     """The oracle (a plain-C port of the reference's kernel) on the host cores, on a stratified sub-sample of the
-    same workload: every `stride`-th pixel in x and y at `cpu_spp` samples per pixel."""
+    same workload: every `stride`-th pixel in x and y at `cpu_spp` samples per pixel, `cpu_runs` times."""
     ora = ge.load_oracle()
     ora.rto_dispatch.restype = None
     ora.rto_dispatch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     import numpy as np
     objs, n = rt.scene(args.scene)
     u = rt.config_uniforms(args.scene, args.width, args.height, args.cpu_spp, args.depth, n)
-    tex = np.zeros((args.height, args.width, 4), np.float32)
-    t0 = time.perf_counter()
-    ora.rto_dispatch(tex.ctypes.data, args.width, args.height, C.byref(u), objs, 0, args.cpu_stride, None)
-    dt = time.perf_counter() - t0
     npx = len(range(0, args.width, args.cpu_stride)) * len(range(0, args.height, args.cpu_stride))
     samples = npx * args.cpu_spp
+    times = []
+    for _ in range(max(1, args.cpu_runs)):
+        tex = np.zeros((args.height, args.width, 4), np.float32)
+        t0 = time.perf_counter()
+        ora.rto_dispatch(tex.ctypes.data, args.width, args.height, C.byref(u), objs, 0, args.cpu_stride, None)
+        times.append(time.perf_counter() - t0)
+    dt = min(times)
     return {
         "value": samples / dt * 1e-6,
         "unit": "Msamples*px/s",
         "cores": int(ora.rto_num_threads()),
         "kind": "port",
-        "sample": "every %dth pixel in x and y of the %dx%d %s frame at %d spp, depth %d (%d samples, %.1f s)"
-                  % (args.cpu_stride, args.width, args.height, args.scene, args.cpu_spp, args.depth, samples, dt),
+        "cpu": cpu_model(),
+        "runs_s": [round(t, 3) for t in times],
+        "sample": "every %dth pixel in x and y of the %dx%d %s frame at %d spp, depth %d (%d samples per run, best of %d runs)"
+                  % (args.cpu_stride, args.width, args.height, args.scene, args.cpu_spp, args.depth, samples, len(times)),
     }
 
 
@@ -109,7 +129,11 @@ def main():
     spec.loader.exec_module(part)
 
     W, H, spp = args.width, args.height, args.spp
-    stream = torch.cuda.current_stream()
+    # One stream of our own for everything: the library's launches, torch's clears and copies, and the collective
+    # (torch orders a collective against the stream that is current when it is called).  The default stream has the
+    # null handle, which the library reads as "create a private stream" -- nothing torch does would be ordered with it.
+    stream = torch.cuda.Stream(device=local_rank)
+    torch.cuda.set_stream(stream)
     r = rt.MetalRenderer(device=local_rank, stream=stream.cuda_stream)
     r.setupTexture(W, H)
     if args.chunk >= 0:
@@ -132,16 +156,18 @@ def main():
         # reduce acts as the gather of disjoint tiles
         begin, end = 0, spp
         y0, y1 = part.tile_rows(rank, world, H)
-        u.tileY, u.tileHeight = y0, max(1, y1 - y0)
         if y1 <= y0:
-            begin = end = 0  # more ranks than tile rows: nothing to trace
+            begin = end = 0  # more ranks than tile rows: nothing to trace, the buffer stays zero
+        else:
+            u.tileY, u.tileHeight = y0, y1 - y0
 
     def step():
         r.accumClear(accum.data_ptr())
-        r.render(u, None, 0, begin, end, accum.data_ptr())
+        if end > begin:
+            r.render(u, None, 0, begin, end, accum.data_ptr())
         if world > 1:
             if args.backend == "nccl":
-                dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI, ordered after the trace on this stream
+                dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI; `stream` is current, so it follows the trace
             else:
                 host = accum.cpu()
                 dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
@@ -174,28 +200,105 @@ def main():
 
     trace_ms = r.traceTimes()
     st = r.lastStats()
+    if args.dump and rank == 0:
+        import numpy as np
+        torch.cuda.synchronize()
+        np.savez(args.dump, accum=accum.cpu().numpy(), image=r.readTexture(), begin=begin, end=end, chunk=st.chunk,
+                 chunk_count=st.chunk_count, tail_chunk=st.tail_chunk)
+
+    # N = 1: the same workload with the vector sphere filter (no matrix instructions), a few steps: the design point
+    # whose arithmetic the FP32 vector peak prices
+    valu = None
+    if world == 1 and args.valu_steps > 0 and st.scene_path in (3, 4):
+        r.set_option(rt.RT_OPT_FILTER, 2)
+        step()
+        fence()
+        r.traceTimes()
+        t1 = time.perf_counter()
+        for _ in range(args.valu_steps):
+            step()
+        fence()
+        dt2 = time.perf_counter() - t1
+        ms2 = r.traceTimes()
+        st2 = r.lastStats()
+        avg2 = sum(ms2) / max(1, len(ms2))
+        tf2 = FLOPS_PER_TEST * st2.tests / (avg2 * 1e-3) * 1e-12 if avg2 > 0 else 0.0
+        valu = {
+            "what": "same workload, RT_OPT_FILTER=2: sphere filter on the vector ALU (9 FMA-class instructions per test), "
+                    "no matrix instructions; %d timed steps" % args.valu_steps,
+            "value": W * H * spp / (dt2 / args.valu_steps) * 1e-6, "unit": "Msamples*px/s",
+            "ms_per_step": dt2 / args.valu_steps * 1e3, "avg_launch_ms": avg2,
+            "achieved": tf2, "peak": FP32_VALU_PEAK_TFLOPS, "unit_achieved": "TFLOP/s (23 flops per ray-object test)",
+            "frac": tf2 / FP32_VALU_PEAK_TFLOPS, "sphere_filter_path": st2.scene_path,
+        }
+        r.set_option(rt.RT_OPT_FILTER, args.filter)
+
     out = None
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         total_samples = W * H * spp
         avg_trace_ms = sum(trace_ms) / max(1, len(trace_ms))
         flops_per_launch = FLOPS_PER_TEST * st.tests
-        achieved = flops_per_launch / (avg_trace_ms * 1e-3) * 1e-12 if avg_trace_ms > 0 else 0.0
+        algorithmic = flops_per_launch / (avg_trace_ms * 1e-3) * 1e-12 if avg_trace_ms > 0 else 0.0
         matrix = st.scene_path in (3, 4)
-        # executed matrix work of one launch: every closest-hit search of a wave multiplies all sphere slots (padded
-        # to 64) with the wave's 64 rays; lanes without a ray ride along, so count searches per lane slot
-        slots64 = (n + 63) // 64 * 64
-        mfma_tflops = (MFMA_FLOPS_PER_PAIR * st.segments * slots64 / (avg_trace_ms * 1e-3) * 1e-12
-                       if matrix and avg_trace_ms > 0 else 0.0)
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_trace_hbm_bytes.json")
+        # Executed matrix work of one launch, counted by the kernel itself: 64-sphere blocks x 64 rays that the waves
+        # put through the filter (lanes without a ray ride along), 8 v_mfma_f32_32x32x16_f16 each.
+        mfma_flops = MFMA_FLOPS_PER_BLOCK * st.matrix_blocks
+        mfma_tflops = mfma_flops / (avg_trace_ms * 1e-3) * 1e-12 if matrix and avg_trace_ms > 0 else 0.0
+        # HBM traffic of the trace kernel is not measurable from inside this process: it is replayed from the counter
+        # run committed under profiles/, and only while that run was taken on this workload and this kernel source.
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "trace_hbm_bytes.json")
         if world == 1 and os.path.exists(pmc_path):
             try:
                 rec = json.load(open(pmc_path))
-                if rec.get("workload") == "%s %dx%d %dspp" % (args.scene, W, H, spp):
+                if (rec.get("workload") == "%s %dx%d %dspp" % (args.scene, W, H, spp)
+                        and rec.get("kernel_source_id") == ge.kernel_source_id()):
                     traffic = rec.get("bytes_per_launch")
+                    traffic_src = "replayed from profiles/trace_hbm_bytes.json (rocprofv3 --pmc run of this workload, kernel source %s)" % rec.get("kernel_source_id")
             except Exception:
                 traffic = None
+        if matrix:
+            roofline = {
+                "bound": "mfma",
+                "achieved": mfma_tflops,
+                "peak": F16_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": mfma_tflops / F16_MFMA_PEAK_TFLOPS,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
+                "kernel": "trace_kernel (rank 0)",
+                "note": "achieved = executed FP16 matrix flops of the conservative sphere filter (kernel-counted 64x64 "
+                        "blocks x 8 instructions x 32768 flop) / launch time, against the dense FP16 matrix peak; the "
+                        "kernel is bound by SIMD issue shared between matrix and vector instructions, so the rest of "
+                        "the time is vector work (sign extraction, exact hit tests, shading)",
+                "mfma_flops_per_launch": mfma_flops,
+            }
+        else:
+            roofline = {
+                "bound": "valu_fp32",
+                "achieved": algorithmic,
+                "peak": FP32_VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": algorithmic / FP32_VALU_PEAK_TFLOPS,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
+                "kernel": "trace_kernel (rank 0)",
+                "note": "achieved counts the reference's 23 flops per ray-object test; the sphere filter runs on the vector ALU",
+            }
+        roofline.update({
+            "sphere_filter": {0: "vector, records staged in LDS", 1: "vector, scalar-cache fetch",
+                              2: "vector, streamed tiles", 3: "matrix cores (v_mfma_f32_32x32x16_f16)",
+                              4: "matrix cores, lifted tiles streamed through LDS"}[st.scene_path],
+            # the reference's brute-force loop priced at 23 flops per ray-object test: a rate of useful work, not a
+            # fraction of any pipe once the filter runs on the matrix cores
+            "algorithmic_tflops": algorithmic,
+            "algorithmic_flops_per_launch": flops_per_launch,
+            "avg_launch_ms": avg_trace_ms,
+            "segments_per_sample": st.segments / max(1, st.samples),
+            "wave_trips": st.wave_trips,
+            "valu_design_point": valu,
+        })
         out = {
             "metric": "Msamples*px/s (whole job), RTiOW cover 1080p; % FP32 VALU peak",
             "value": total_samples / (ms_per_step * 1e-3) * 1e-6,
@@ -216,30 +319,9 @@ def main():
                 "parallelism": ("sample-index split x%d, RCCL reduce of float4 accumulation buffers" % world)
                                if args.partition == "sample" else
                                ("rows of 64-pixel tiles split x%d, RCCL reduce as gather" % world),
+                "kernel_source_id": ge.kernel_source_id(),
             },
-            "roofline": {
-                "bound": "valu_fp32",
-                "achieved": achieved,
-                "peak": FP32_VALU_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / FP32_VALU_PEAK_TFLOPS,
-                "traffic": traffic,
-                "kernel": "trace_kernel (rank 0)",
-                "note": ("achieved counts the reference's 23 flops per ray-object test; the conservative sphere filter "
-                         "runs on the matrix cores (FP16-pair K=32 product per test, lower bound below: idle lanes "
-                         "not counted), so frac can exceed 1 against the FP32 vector peak") if matrix else
-                        "achieved counts the reference's 23 flops per ray-object test",
-                "sphere_filter": {0: "vector, records staged in LDS", 1: "vector, scalar-cache fetch",
-                                  2: "vector, streamed tiles", 3: "matrix cores (v_mfma_f32_32x32x16_f16)",
-                                  4: "matrix cores, lifted tiles streamed through LDS"}[st.scene_path],
-                "mfma_executed": {"tflops": mfma_tflops, "peak": F16_MFMA_PEAK_TFLOPS,
-                                  "frac": mfma_tflops / F16_MFMA_PEAK_TFLOPS} if matrix else None,
-                "flops_per_launch": flops_per_launch,
-                "avg_launch_ms": avg_trace_ms,
-                "segments_per_sample": st.segments / max(1, st.samples),
-                "pct_valu_peak_whole_job": 100.0 * FLOPS_PER_TEST * st.tests * world / (ms_per_step * 1e-3) * 1e-12
-                                           / (FP32_VALU_PEAK_TFLOPS * world),
-            },
+            "roofline": roofline,
         }
     if world > 1:
         dist.barrier()

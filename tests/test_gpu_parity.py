@@ -310,6 +310,147 @@ def test_bench_configuration_spot_pixels(rt, oracle, renderer):
         assert np.array_equal(bits(img[y, x]), bits(want)), (x, y)
 
 
+def oracle_spot_pixels(oracle, u, objs, pixels, ranges, workers=8):
+    """Linear sums of the given pixels as the kernel forms them: each range summed sample by sample, the range sums
+    added in order.  The oracle's per-sample call releases the GIL, so the pixels are spread over a few threads."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(xy):
+        x, y = xy
+        acc = np.zeros(4, np.float32)
+        for b, e in ranges:
+            part = np.zeros(4, np.float32)
+            for k in range(b, e):
+                c = (C.c_float * 4)()
+                if oracle.lib.rto_sample(C.byref(u), objs, x, y, k, c, None):
+                    part = part + np.array(list(c), np.float32)
+            acc = acc + part
+        return acc
+
+    with ThreadPoolExecutor(workers) as pool:
+        return list(pool.map(one, pixels))
+
+
+def test_100k_sphere_configuration_spot_pixels(rt, oracle, renderer):
+    """The 100 000-sphere configuration at its own size -- 1920x1080, 64 spp, depth 50, default options (lifted tiles
+    streamed through LDS, matrix-core filter, spheres visited in spatial order) -- at 24 scattered pixels against the
+    oracle's brute-force loop over all objects (Shaders.metal:13-32), bit for bit."""
+    for opt in (rt.RT_OPT_SCENE_FETCH, rt.RT_OPT_FILTER, rt.RT_OPT_BLOCKS_PER_CU):
+        renderer.set_option(opt, 0)
+    for opt in (rt.RT_OPT_CHUNK, rt.RT_OPT_TAIL_CHUNK, rt.RT_OPT_TAIL_SAMPLES):
+        renderer.set_option(opt, -1)
+    w, h, spp = 1920, 1080, 64
+    objs, n = rt.scene("random_spheres")
+    assert n >= 100000
+    u = rt.config_uniforms("random_spheres", w, h, spp, 50, n)
+    renderer.setupTexture(w, h)
+    renderer.setScene(objs, n)
+    renderer.accumClear()
+    renderer.render(u, None, 0, 0, spp)
+    renderer.resolve(spp)
+    img = renderer.readTexture()
+    st = renderer.lastStats()
+    assert st.scene_path == 4 and st.samples == w * h * spp and st.tests == st.segments * n
+    ranges = st.chunk_ranges(0, spp)
+    assert ranges[0][0] == 0 and ranges[-1][1] == spp and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    rng = np.random.RandomState(5)
+    pixels = [(int(rng.randint(0, w)), int(rng.randint(0, h))) for _ in range(24)]
+    sums = oracle_spot_pixels(oracle, u, objs, pixels, ranges)
+    seen = set()
+    for (x, y), acc in zip(pixels, sums):
+        want = oracle.resolve(acc.reshape(1, 1, 4), spp)[0, 0]
+        assert np.array_equal(bits(img[y, x]), bits(want)), (x, y)
+        seen.add(tuple(want))
+    assert len(seen) > 12  # the pixels see different things: not all sky
+
+
+def test_4k_cover_per_rank_share_spot_pixels(rt, oracle, renderer):
+    """The 3840x2160 x 1000 spp cover configuration as one rank of eight traces it: all pixels, the sample indices
+    ray_range(rank, 8, 1000), default options, for the first and the last rank; 16 scattered pixels' linear sums each
+    against the oracle, bit for bit (the seed expression of Shaders.metal:121-126 exceeds 2^24 here)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rt_partition", os.path.join(HERE, "..", "ray-tracing_amd", "partition.py"))
+    part = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(part)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    for opt in (rt.RT_OPT_SCENE_FETCH, rt.RT_OPT_FILTER, rt.RT_OPT_BLOCKS_PER_CU):
+        renderer.set_option(opt, 0)
+    for opt in (rt.RT_OPT_CHUNK, rt.RT_OPT_TAIL_CHUNK, rt.RT_OPT_TAIL_SAMPLES):
+        renderer.set_option(opt, -1)
+    w, h, spp = 3840, 2160, 1000
+    objs, n = rt.scene("cover")
+    u = rt.config_uniforms("cover", w, h, spp, 50, n)
+    assert u.defocusAngle > 0
+    renderer.setupTexture(w, h)
+    renderer.setScene(objs, n)
+    rng = np.random.RandomState(17)
+    for rank in (0, 7):
+        begin, end = part.ray_range(rank, 8, spp)
+        assert end - begin == 125
+        renderer.accumClear()
+        renderer.render(u, None, 0, begin, end)
+        st = renderer.lastStats()
+        assert st.scene_path == 3 and st.samples == w * h * 125
+        sums = np.empty((h, w, 4), np.float32)
+        renderer.synchronize()
+        assert hip.hipMemcpy(sums.ctypes.data, renderer.accumPtr(), sums.nbytes, 2) == 0
+        ranges = st.chunk_ranges(begin, end)
+        assert ranges[0][0] == begin and ranges[-1][1] == end
+        pixels = [(int(rng.randint(0, w)), int(rng.randint(0, h))) for _ in range(14)] + [(w - 1, h - 1), (0, h - 1)]
+        for (x, y), acc in zip(pixels, oracle_spot_pixels(oracle, u, objs, pixels, ranges)):
+            assert np.array_equal(bits(sums[y, x]), bits(acc)), (rank, x, y)
+    renderer.setupTexture(64, 64)  # give the 4K buffers back
+
+
+def test_bench_two_ranks_real_path(rt, tmp_path):
+    """bench.py's own multi-rank step -- per-rank sample range, trace, reduce to rank 0, resolve -- run as two
+    processes (one GPU each when two are visible, else both on GPU 0 with the gloo backend), against the same two
+    ranges traced here by one process and added in the same order: rank 0's reduced sums and image, bit for bit."""
+    import subprocess
+    import torch
+    root = os.path.dirname(HERE)
+    w, h, spp = 320, 180, 24
+    dump = str(tmp_path / "two_ranks.npz")
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    port = 29600 + (os.getpid() % 1000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--width", str(w), "--height", str(h), "--spp", str(spp), "--backend", backend, "--dump", dump]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=170)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    import json
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["samples_per_rank"] == spp // 2 and line["value"] > 0
+    got = np.load(dump)
+
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    r = rt.MetalRenderer(device=0)
+    try:
+        objs, n = rt.scene("cover")
+        u = rt.config_uniforms("cover", w, h, spp, 50, n)
+        r.setupTexture(w, h)
+        r.setScene(objs, n)
+        parts = []
+        for begin, end in ((0, spp // 2), (spp // 2, spp)):
+            r.accumClear()
+            r.render(u, None, 0, begin, end)
+            r.synchronize()
+            a = np.empty((h, w, 4), np.float32)
+            assert hip.hipMemcpy(a.ctypes.data, r.accumPtr(), a.nbytes, 2) == 0
+            parts.append(a)
+        st = r.lastStats()
+        assert (st.chunk, st.chunk_count) == (int(got["chunk"]), int(got["chunk_count"]))
+    finally:
+        r.close()
+    want = parts[0] + parts[1]
+    assert want.any() and np.array_equal(bits(got["accum"]), bits(want))
+    from conftest import Oracle
+    assert np.array_equal(bits(got["image"]), bits(Oracle().resolve(want, spp)))
+
+
 def test_4k_seed_rounding_spot_pixels(rt, oracle, renderer):
     """At 3840x2160 the integer seed expression exceeds 2^24 and is rounded on conversion to float."""
     strict(renderer, rt)

@@ -35,6 +35,29 @@ def test_c_header_compiles_as_c_and_cpp():
         subprocess.run([cc, "-x", lang, "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-"], input=src.encode(), check=True)
 
 
+def test_module_map_builds_and_imports(tmp_path):
+    """include/module.modulemap is what replaces the reference's bridging header (project.pbxproj:438): clang builds the
+    module RTAmd from it and a translation unit gets the ABI structs and the entry points through `@import RTAmd`
+    (Objective-C syntax, the route Swift's importer takes) and through an #include that the map turns into an import."""
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    if not os.path.exists(clang):
+        import pytest
+        pytest.skip("no clang")
+    base = [clang, "--target=x86_64-unknown-linux-gnu", "-fmodules", "-fimplicit-module-maps",
+            "-fmodules-cache-path=" + str(tmp_path / "cache"), "-I", os.path.join(ROOT, "include"), "-fsyntax-only", "-Werror"]
+    body = ("int f(void) { struct Uniforms u; struct Object o; struct rt_stats s; (void)u; (void)o; (void)s;\n"
+            "  _Static_assert(sizeof(struct Object) == 160 && sizeof(struct Uniforms) == 224, \"ABI\");\n"
+            "  return RT_OK + (&rt_render_tile != 0) + (&rt_render_noalloc != 0) + (int)TYPE_QUAD + (int)DIELECTRIC; }\n")
+    objc = tmp_path / "use.m"
+    objc.write_text("@import RTAmd;\n" + body)
+    subprocess.run(base + ["-Wno-tautological-pointer-compare", "-x", "objective-c", str(objc)], check=True)
+    c = tmp_path / "use.c"
+    c.write_text('#include "rt_amd.h"\n' + body)
+    res = subprocess.run(base + ["-Wno-tautological-pointer-compare", "-Rmodule-import", str(c)], check=True,
+                         capture_output=True, text=True)
+    assert "importing module 'RTAmd'" in res.stderr  # the include went through the module, not the text of the header
+
+
 def test_libraries_export_every_declared_symbol(rt):
     amd, host = rt.amd_lib(), rt.host_lib()
     for s in rt.AMD_SYMBOLS:
