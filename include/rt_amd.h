@@ -78,7 +78,10 @@ enum {
                                longer items, so that the persistent grid drains evenly; -1 (default) and 0 = no such
                                tail (measured on the cover scene: it costs more in camera-ray generation than the
                                even drain gains) */
-    RT_OPT_TAIL_SAMPLES = 9 /* samples per pixel in that tail; -1 (default) = automatic */
+    RT_OPT_TAIL_SAMPLES = 9, /* samples per pixel in that tail; -1 (default) = automatic */
+    RT_OPT_RESOLVE = 10     /* how the exact hit test walks the candidates the sphere filter left (LDS-staged scenes;
+                               results are identical): 0 = chosen per wave (default), 1 = always pooled over the wave,
+                               2 = always lane by lane, two candidates in flight */
 };
 
 /* setupMetal (ContentView.swift:328-356): device, queue, pipelines.  `device` is the HIP device ordinal.

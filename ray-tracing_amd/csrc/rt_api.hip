@@ -90,6 +90,7 @@ struct rt_ctx {
     int opt_fetch = 0;
     int opt_blocks_per_cu = 0;
     int opt_filter = 0;
+    int opt_resolve = 0;
     int opt_wf_slots = 1 << 20;
 
     rt_stats last = {};
@@ -542,6 +543,7 @@ void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
     P.ntiles = ctx->ntiles;
     P.lift = ctx->lift;
     P.nobj = ctx->nobj;
+    P.resolve_mode = ctx->opt_resolve;
     P.width = ctx->width;
     P.height = ctx->height;
     P.pass = u->currentSample;
@@ -746,6 +748,10 @@ RT_API int rt_set_option(rt_ctx *ctx, int key, int value) {
             if (value < 0 || value > 3) return fail(ctx, RT_ERR_INVALID, "rt: filter must be 0, 1, 2 or 3");
             ctx->opt_filter = value;
             return RT_OK;
+        case RT_OPT_RESOLVE:
+            if (value < 0 || value > 2) return fail(ctx, RT_ERR_INVALID, "rt: resolve form must be 0, 1 or 2");
+            ctx->opt_resolve = value;
+            return RT_OK;
         case RT_OPT_WAVEFRONT_SLOTS:
             if (value < 256 || value > (1 << 24)) return fail(ctx, RT_ERR_INVALID, "rt: wavefront slots out of range");
             ctx->opt_wf_slots = value / 256 * 256;
@@ -764,6 +770,7 @@ RT_API int rt_get_option(const rt_ctx *ctx, int key, int *value) {
         case RT_OPT_SCENE_FETCH: *value = ctx->opt_fetch; return RT_OK;
         case RT_OPT_BLOCKS_PER_CU: *value = ctx->opt_blocks_per_cu; return RT_OK;
         case RT_OPT_FILTER: *value = ctx->opt_filter; return RT_OK;
+        case RT_OPT_RESOLVE: *value = ctx->opt_resolve; return RT_OK;
         case RT_OPT_WAVEFRONT_SLOTS: *value = ctx->opt_wf_slots; return RT_OK;
     }
     return RT_ERR_INVALID;

@@ -161,6 +161,9 @@ struct RootDiv {
     bool slow;  // wave-uniform: a ray of this wave has a outside [2^-40, 2^40]; everybody divides the ordinary way
     RT_DEV float quotient(float n) const {
         if (slow) return n / a;
+        return quotient_fast(n);
+    }
+    RT_DEV float quotient_fast(float n) const {  // callers have checked !slow
         float q = n * r;
         float e = __builtin_fmaf(-a, q, n);
         q = __builtin_fmaf(e, r, q);

@@ -18,6 +18,7 @@ constexpr int kRoundWords = 16;   // candidate words per resolve round (512 sphe
 constexpr int kListOffset = kRoundWords * 64;        // after a wave's candidate words: 64 words of candidate list ...
 constexpr int kBestOffset = kListOffset + 64;        // ... and 64 x 64 bits of (distance, slot) minima (resolve_balanced)
 constexpr int kMaskWordsPerWave = kBestOffset + 128; // LDS words per wave
+constexpr int kDenseWordBits = 8;  // candidates in a word of 32 spheres from which the word counts as dense (closest_sphere)
 
 // Filter margins (see closest_sphere).  kDirScale inflates the b side of both filters; the c side is inflated
 // on the host when the records are built: r*r * (1 + 2^-17) in the general records, and a slack of
@@ -222,6 +223,7 @@ struct Prof {
 // took part in, and 64-sphere blocks it put through the matrix-core filter (8 matrix instructions each).
 struct Work {
     uint32_t trips = 0, blocks = 0;
+    bool dense = false;  // the wave's last closest-hit search had dense candidate words (closest_sphere)
 };
 
 // Per-ray constants of the two filters.
@@ -586,6 +588,120 @@ RT_DEV void resolve_balanced(const F &f, uint32_t *wave_masks, uint32_t nz, int 
     }
 }
 
+// Pass B for slots that are in object order, every lane resolving its own candidates.  It is the form for waves whose
+// lanes all hold long lists (rays that cross many nested shells: 170 candidates per ray), where pooling has nothing
+// to balance and pays for its list, its cross-lane reads and its LDS minima.  What limits a per-lane loop is the
+// length of one candidate's dependent chain (record read, discriminant, square root, division), so four candidates
+// are in flight at a time -- the two highest and the two lowest set bits of the current word -- and their code has
+// no branches: every lane runs the same instructions anyway.  Four at once is possible because the root a sphere
+// offers does not depend on the best distance so far (see resolve_balanced), so the lane's answer is the minimum
+// over (distance, slot) in any visiting order; the running best only serves to discard numerators above its own
+// ("not above" in place of the reference's "below", so that an equal distance at a lower slot is still seen).  When
+// a word has fewer than four bits left some chains resolve the same candidate twice, which changes nothing.
+struct LaneBest {
+    float t;        // smallest accepted root so far (tbest on entry)
+    uint32_t slot;  // its slot, 0xFFFFFFFF while none
+    float n;        // its numerator (root * a up to rounding), +inf while none
+};
+struct LaneRoot {
+    bool ok, retry;  // retry: the first root exists but is not above kTMin, so the second has to be looked at
+    float root, n, n2;
+};
+// Lib.metal:216-238 for one candidate without branches.  The root the reference would take is the first one if it is
+// above kTMin, else the second if that is; numerators at or below dv.nmin give quotients below kTMin without
+// dividing (RootDiv).  A negative discriminant makes every numerator NaN, and a NaN passes no comparison.
+RT_DEV LaneRoot lane_root(f4v rec, V3 o, V3 d, const RootDiv &dv, float nprune) {  // rec = (center, radius)
+    float ocx = o.x - rec.x, ocy = o.y - rec.y, ocz = o.z - rec.z;
+    float b = ocx * d.x + ocy * d.y + ocz * d.z;
+    float c = (ocx * ocx + ocy * ocy + ocz * ocz) - rec.w * rec.w;
+    float disc = b * b - dv.a * c;
+    float sqrtd = __builtin_sqrtf(disc);
+    LaneRoot r;
+    const float n1 = -b - sqrtd;
+    r.n2 = -b + sqrtd;
+    const bool first = n1 > dv.nmin;
+    r.n = first ? n1 : r.n2;
+    r.root = dv.quotient_fast(r.n);
+    const bool above = kTMin < r.root;
+    // (bitwise operators: no short-circuit branches, the four candidates of a turn stay in one basic block)
+    r.ok = (r.n > dv.nmin) & (r.n <= nprune) & above & !(disc < 0.0f);
+    r.retry = first & !above & !(disc < 0.0f);
+    return r;
+}
+RT_DEV void lane_offer(LaneBest &best, const LaneRoot &r, uint32_t slot) {
+    const bool better = r.ok & ((r.root < best.t) | ((r.root == best.t) & (slot < best.slot)));
+    best.t = better ? r.root : best.t;
+    best.slot = better ? slot : best.slot;
+    best.n = better ? r.n : best.n;
+}
+// The rare second look: the first root was a hair below kTMin although its numerator was above dv.nmin.
+RT_DEV void lane_retry(LaneBest &best, const LaneRoot &r, uint32_t slot, const RootDiv &dv, float nprune) {
+    if (r.retry && r.n2 > dv.nmin && r.n2 <= nprune) {
+        const float root = dv.quotient_fast(r.n2);
+        if (kTMin < root && (root < best.t || (root == best.t && slot < best.slot))) {
+            best.t = root;
+            best.slot = slot;
+            best.n = r.n2;
+        }
+    }
+}
+// One candidate word (32 spheres from slot `base` on) of every lane, four candidates per turn.
+template <typename F, bool PROF>
+RT_DEV void resolve_word_per_lane(const F &f, uint32_t m, int base, V3 o, V3 d, const RootDiv &dv, LaneBest &best, Prof<PROF> &prof) {
+    while (m) {
+        // positions in the word (0 = first sphere): the two highest and the two lowest set bits
+        const int p0 = __builtin_clz(m), p3 = 31 - __builtin_ctz(m);
+        const uint32_t m1 = m & ~((0x80000000u >> p0) | (0x80000000u >> p3));
+        const int p1 = m1 ? __builtin_clz(m1) : p0, p2 = m1 ? 31 - __builtin_ctz(m1) : p3;
+        m = m1 & ~((0x80000000u >> p1) | (0x80000000u >> p2));
+        if constexpr (PROF) {
+            prof.count(6);
+            prof.count(7, (uint64_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) * 4);
+        }
+        const float nprune = best.n;
+        // all four records are asked for before the first is used (the statement below keeps the reads together)
+        f4v c0 = f.load1(base + p0), c1 = f.load1(base + p1), c2 = f.load1(base + p2), c3 = f.load1(base + p3);
+        asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+        const LaneRoot r0 = lane_root(c0, o, d, dv, nprune);
+        const LaneRoot r1 = lane_root(c1, o, d, dv, nprune);
+        const LaneRoot r2 = lane_root(c2, o, d, dv, nprune);
+        const LaneRoot r3 = lane_root(c3, o, d, dv, nprune);
+        lane_offer(best, r0, (uint32_t)(base + p0));
+        lane_offer(best, r1, (uint32_t)(base + p1));
+        lane_offer(best, r2, (uint32_t)(base + p2));
+        lane_offer(best, r3, (uint32_t)(base + p3));
+        if (__builtin_amdgcn_ballot_w64(r0.retry || r1.retry || r2.retry || r3.retry)) {
+            lane_retry(best, r0, (uint32_t)(base + p0), dv, nprune);
+            lane_retry(best, r1, (uint32_t)(base + p1), dv, nprune);
+            lane_retry(best, r2, (uint32_t)(base + p2), dv, nprune);
+            lane_retry(best, r3, (uint32_t)(base + p3), dv, nprune);
+        }
+    }
+}
+
+// The words of a round that are dense in most lanes are resolved per lane and struck from nz; the others are left to
+// the pooled form.  all = true: every word per lane.
+template <typename F, bool PROF>
+RT_DEV uint32_t resolve_dense_words(const F &f, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, V3 o, V3 d, const RootDiv &dv,
+                                    bool all, LaneBest &best, Prof<PROF> &prof) {
+    // words that are non-empty in some lane (wave-uniform)
+    uint32_t any = nz;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) any |= (uint32_t)__shfl_xor((int)any, off, 64);
+    any = (uint32_t)__builtin_amdgcn_readfirstlane((int)any);
+    while (any) {
+        const int w = __builtin_ctz(any);
+        any &= any - 1;
+        const uint32_t m = (nz >> w) & 1u ? wave_masks[w * 64 + lane] : 0u;
+        const uint64_t dense = __builtin_amdgcn_ballot_w64(__builtin_popcount(m) >= kDenseWordBits);
+        if (all || __builtin_popcountll(dense) >= 32) {
+            resolve_word_per_lane(f, m, slot0 + w * 32, o, d, dv, best, prof);
+            nz &= ~(1u << w);
+        }
+    }
+    return nz;
+}
+
 // Closest sphere hit of ray (o, d) over all spheres: the sphere part of world_hit (Shaders.metal:13-32) with
 // hitSphere (Lib.metal:215-246).  Returns the sphere slot or -1; t in tbest.  Must be called by all 64 lanes of the
 // wave (the streaming fetcher loads tiles cooperatively); lanes without a ray pass active = false and get -1.
@@ -624,6 +740,7 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
     // every lane's closest (distance, slot) so far, kept in LDS where other lanes can lower it (resolve_balanced)
     unsigned long long *best = (unsigned long long *)(wave_masks + kBestOffset);
     best[lane] = ((unsigned long long)__float_as_uint(tbest) << 32) | 0xFFFFFFFFull;
+    LaneBest lane_best = {tbest, 0xFFFFFFFFu, __builtin_inff()};
     f.start(general);
     for (int g0 = 0; g0 < P.ngroups; g0 += kRoundWords * kWordGroups) {
         const int g1 = min(P.ngroups, g0 + kRoundWords * kWordGroups);
@@ -652,12 +769,32 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
         }
         if (!a_ok || !active) nz = 0;
         prof.lap(1);
+        // Which form of pass B: pooled over the wave (the usual case: a couple of candidates per ray, a few lanes with
+        // more), except for words of 32 spheres in which most lanes hold many candidates (nested shells): those go lane
+        // by lane.  Looking for such words costs a pass over the words, so it is only done when a quarter of the lanes
+        // have three or more non-empty words and the first of them is dense; and a wave that found no such round asks
+        // again only on every eighth of its searches.  (A wave with a ray whose a = d.d is out of the range of the
+        // shared-reciprocal division stays pooled.)
+        if (P.resolve_mode != 1 && !dv.slow) {
+            bool look = P.resolve_mode == 2;
+            if (!look && (work.dense || (work.trips & 7u) == 0u)) {
+                if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(__builtin_popcount(nz) >= 3)) >= 16) {
+                    const uint32_t first = nz ? wave_masks[__builtin_ctz(nz) * 64 + lane] : 0u;
+                    look = __builtin_popcountll(__builtin_amdgcn_ballot_w64(__builtin_popcount(first) >= kDenseWordBits)) >= 16;
+                }
+                work.dense = look;
+            }
+            if (look) nz = resolve_dense_words(f, wave_masks, nz, 4 * g0, lane, o, d, dv, P.resolve_mode == 2, lane_best, prof);
+        }
         resolve_balanced(f, wave_masks, nz, 4 * g0, lane, o, d, dv, prof);
         prof.lap(2);
     }
+    // the answer is the smaller of what the two forms found (equal distances: the lower slot)
     const unsigned long long r = best[lane];
-    tbest = __uint_as_float((uint32_t)(r >> 32));
-    return (int)(uint32_t)r;  // 0xFFFFFFFF = -1: no hit
+    const unsigned long long r2 = ((unsigned long long)__float_as_uint(lane_best.t) << 32) | lane_best.slot;
+    const unsigned long long rr = r2 < r ? r2 : r;
+    tbest = __uint_as_float((uint32_t)(rr >> 32));
+    return (int)(uint32_t)rr;  // 0xFFFFFFFF = -1: no hit
 }
 
 // Asynchronous copy of tile t (count spheres) into LDS buffer b: every wave of the workgroup copies 1 KiB pieces,

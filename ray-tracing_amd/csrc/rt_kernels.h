@@ -46,6 +46,8 @@ struct TraceParams {
     int ntiles;
     int stage_mats;         // matrix-core kind: sph_obj and mats are staged in LDS too (the launch reserved the room)
     int nobj;               // objects (length of mats)
+    int resolve_mode;       // exact pass over the candidates: 0 chosen per wave and round, 1 always pooled over the wave,
+                            // 2 always per lane (rt_hit.hpp closest_sphere)
     float4 *rayq;           // per-wave queues of generated camera rays: grid lanes x kQueueRays x 2 float4
     int maxDepth;           // Uniforms.maxRayDepth
     V4 sky;                 // Uniforms.globalIllumation

@@ -19,6 +19,7 @@ for name, kw, w, h, spp, depth in cases:
     r.set_option(rt.RT_OPT_SCENE_FETCH, int(os.environ.get('FETCH', '0')))
     r.set_option(rt.RT_OPT_CHUNK, int(os.environ.get('CHUNK', '-1')))
     r.set_option(rt.RT_OPT_TAIL_CHUNK, int(os.environ.get('TAIL', '-1')))
+    r.set_option(rt.RT_OPT_RESOLVE, int(os.environ.get('RESOLVE', '0')))
     u = rt.config_uniforms(name, w, h, spp, depth, n)
     for kernel in (0, 2):
         r.set_option(rt.RT_OPT_KERNEL, kernel)
