@@ -28,10 +28,11 @@ oracle:
 	$(MAKE) -C oracle
 
 # instruction-rate and matrix-core probes behind the design (profiles/r01_*.txt are their outputs)
-TOOLS = tools/valu_rate tools/mfma_coexec tools/mfma_f16_probe tools/mfma_split_probe tools/op_rate tools/div_probe
+TOOLS = tools/valu_rate tools/mfma_coexec tools/mfma_f16_probe tools/mfma_split_probe tools/op_rate tools/div_probe \
+        tools/filter_probe tools/mfma_hazard_probe
 tools: $(TOOLS)
-tools/%: tools/%.hip
-	$(HIPCC) --offload-arch=gfx950 -O3 -ffp-contract=off -o $@ $<
+tools/%: tools/%.hip $(HIP_HDRS)
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -Iinclude -o $@ $<
 
 host: $(LIBDIR)/librt_host.so
 

@@ -125,7 +125,8 @@ def amd_lib():
     """librt_amd.so (HIP kernels + C-ABI).  Raises OSError if it has not been built."""
     global _amd
     if _amd is None:
-        lib = C.CDLL(os.path.join(LIB_DIR, "librt_amd.so"))
+        # RT_AMD_LIB: another build of the same library, for A/B measurements (tools/)
+        lib = C.CDLL(os.environ.get("RT_AMD_LIB") or os.path.join(LIB_DIR, "librt_amd.so"))
         vp, ip, fp = C.c_void_p, C.c_int, C.POINTER(C.c_float)
         lib.rt_create.argtypes = [C.POINTER(vp), ip, vp]
         lib.rt_destroy.argtypes = [vp]

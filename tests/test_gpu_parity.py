@@ -25,6 +25,7 @@ def strict(r, rt, chunk=0, fetch=0):
     r.set_option(rt.RT_OPT_TAIL_CHUNK, -1)
     r.set_option(rt.RT_OPT_TAIL_SAMPLES, -1)
     r.set_option(rt.RT_OPT_BLOCKS_PER_CU, 0)
+    r.set_option(rt.RT_OPT_RESOLVE, 0)
 
 
 def test_committed_images_bit_exact(rt, renderer):
@@ -794,6 +795,25 @@ def test_kernel_variants_bit_exact(rt, oracle, renderer, opt, val):
     finally:
         renderer.set_option(getattr(rt, opt), 0)
     assert np.array_equal(bits(img), bits(want))
+
+
+@pytest.mark.parametrize("name,w,h,spp,depth", [("nested_glass", 160, 90, 4, 100), ("cover", 240, 135, 16, 50)])
+def test_exact_pass_forms_bit_exact(rt, oracle, renderer, name, w, h, spp, depth):
+    """The exact hit test over the filter's candidates pooled over the wave (1), lane by lane with four candidates in
+    flight (2) and chosen per wave (0: lane by lane where candidate words are dense, as in the nested shells) all give
+    the oracle's bits."""
+    strict(renderer, rt)
+    objs, n = rt.scene(name)
+    u = rt.config_uniforms(name, w, h, spp, depth, n)
+    renderer.setupTexture(w, h)
+    want = oracle.image(u, objs, w, h)
+    for mode in (1, 2, 0):
+        renderer.set_option(rt.RT_OPT_RESOLVE, mode)
+        try:
+            img = renderer.renderImage(u, objs, n)
+        finally:
+            renderer.set_option(rt.RT_OPT_RESOLVE, 0)
+        assert np.array_equal(bits(img), bits(want)), mode
 
 
 @pytest.mark.parametrize("name,w,h,spp,depth,slots", [("cornell", 120, 96, 8, 10, 1 << 20), ("nested_glass", 96, 54, 4, 100, 2048),
