@@ -43,6 +43,8 @@ constexpr size_t kScratchBytes = kScratchPlaneOffset + kScratchPlaneBytes;
 constexpr int kScratchMaxDevices = 64;
 }  // namespace
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+// rt_render_tile: largest set of per-sample planes (tile pixels x samples x 16 bytes) it will allocate
+constexpr size_t kTilePlaneBytesMax = (size_t)512 << 20;
 
 struct rt_ctx {
     int device = 0;
@@ -858,13 +860,36 @@ RT_API int rt_render_tile(rt_ctx *ctx, const Uniforms *u, const Object *objs, in
         P.tileX = u->tileX; P.tileY = u->tileY; P.tileW = tw; P.tileH = th;
         P.ray_begin = 0;
         P.ray_end = u->sampleCount > 0 ? u->sampleCount : 0;
-        P.chunk = P.chunk_small = P.ray_end > 0 ? P.ray_end : 1;
-        P.nbig = 1;
-        P.nitems = (uint32_t)tw * (uint32_t)th;
-        P.mode = kModeProgressive;
         P.spp_pass = u->sampleCount;
-        RT_TRY(enqueue_trace(ctx, P));
-        ctx->last.samples = (uint64_t)P.nitems * (uint64_t)P.ray_end;
+        // The reference sums a pixel's samples one after the other (Shaders.metal:120-140), and a 64 x 64 tile has 4096
+        // pixels for a GPU of 262 144 lanes.  So every sample is a work item of its own, its colour goes to a plane of
+        // the tile (plane k = sample k), and a second kernel adds the planes in sample order -- the same additions in the
+        // same order -- and applies the pass's blend.  When the planes would be too large (a "tile" that is a whole
+        // frame with thousands of samples) a pixel's samples stay in one item and the kernel blends by itself.
+        const size_t plane_bytes = (size_t)P.ray_end * (size_t)tw * (size_t)th * sizeof(float4);
+        if (P.ray_end > 1 && plane_bytes <= kTilePlaneBytesMax && (unsigned long long)P.ray_end * tw * th <= 0xF0000000ull) {
+            RT_TRY(grow(ctx, ctx->planes, plane_bytes / sizeof(float4)));
+            P.chunk = P.chunk_small = 1;
+            P.nbig = P.ray_end;
+            P.nitems = (uint32_t)((unsigned long long)P.ray_end * tw * th);
+            P.mode = kModeAccum;
+            P.planes = ctx->planes.ptr;
+            P.plane_x0 = P.tileX; P.plane_y0 = P.tileY; P.plane_w = tw;
+            P.plane_stride = (unsigned long long)tw * th;
+            RT_TRY(enqueue_trace(ctx, P));
+            RT_HIP(launch_blend_tile(ctx->target.ptr, P.planes, P.ray_end, ctx->width, P.tileX, P.tileY, tw, th, P.pass, P.spp_pass,
+                                     ctx->stream));
+            ctx->last.chunk = 1;
+            ctx->last.chunk_count = P.ray_end;
+            ctx->last.tail_chunk = 1;
+        } else {
+            P.chunk = P.chunk_small = P.ray_end > 0 ? P.ray_end : 1;
+            P.nbig = 1;
+            P.nitems = (uint32_t)tw * (uint32_t)th;
+            P.mode = kModeProgressive;
+            RT_TRY(enqueue_trace(ctx, P));
+        }
+        ctx->last.samples = (uint64_t)tw * th * (uint64_t)P.ray_end;
     }
     RT_HIP(hipStreamSynchronize(ctx->stream));
     return status;
@@ -965,6 +990,8 @@ static int render_batch(rt_ctx *ctx, const Uniforms *u, const Object *objs, int 
     P.nitems = (uint32_t)nitems;
     P.mode = kModeAccum;
     P.planes = planes;
+    P.plane_x0 = 0; P.plane_y0 = 0; P.plane_w = ctx->width;
+    P.plane_stride = (unsigned long long)ctx->width * ctx->height;
     RT_TRY(enqueue_trace(ctx, P, noalloc));
     ctx->last.samples = (uint64_t)u->tileWidth * u->tileHeight * (uint64_t)nrays;
     ctx->last.chunk = chunk;

@@ -66,7 +66,11 @@ struct TraceParams {
                                       // counts of the diagnostic instantiation; [9] += closest-hit searches counted
                                       // per wave (idle lanes ride along); [10] += 64-sphere blocks the waves put
                                       // through the matrix-core filter
-    float4 *planes;         // kModeAccum: [nchunks][width*height] partial sums, one plane per chunk
+    float4 *planes;         // kModeAccum: [nchunks][plane_stride] partial sums, one plane per chunk; pixel (x, y) of a
+                            // plane is at (y - plane_y0) * plane_w + (x - plane_x0): planes cover the whole target
+                            // (0, 0, width) or just the tile of the launch
+    int plane_x0, plane_y0, plane_w;
+    unsigned long long plane_stride;
     float4 *target;         // kModeProgressive: rgba32Float render target
     int mode;
     int spp_pass;           // kModeProgressive: Uniforms.sampleCount
@@ -101,6 +105,10 @@ hipError_t launch_matrix_selftest(uint32_t seed, int blocks, int rounds, float s
                                   hipStream_t stream);
 hipError_t launch_fold(float4 *accum, const float4 *planes, int nplanes, int width, int height, int tileX, int tileY,
                        int tileW, int tileH, hipStream_t stream);
+// The reference's per-pixel epilogue for one pass over a tile (Shaders.metal:142-160) on tile-sized planes that hold one
+// sample each: sequential sum in sample order, mean, progressive blend with the target, write_color.
+hipError_t launch_blend_tile(float4 *target, const float4 *planes, int nplanes, int width, int tileX, int tileY, int tileW,
+                             int tileH, int pass, int spp_pass, hipStream_t stream);
 hipError_t launch_resolve(float4 *target, const float4 *accum, int npix, int spp, hipStream_t stream);
 hipError_t launch_fill_rect(float4 *target, int width, int height, int x0, int y0, int w, int h, float4 value,
                             hipStream_t stream);

@@ -27,6 +27,40 @@ __global__ void fold_kernel(float4 *__restrict__ accum, const float4 *__restrict
     accum[p] = a;
 }
 
+// One pass of the reference's kernel over a tile, from per-sample planes of the tile (plane k = sample k, pixel (x, y) of
+// the tile at y * tileW + x): passAccumulator += sample in sample order (Shaders.metal:120-140; a skipped sample's plane
+// holds zeros), /= sampleCount (:142), blend with the gamma-encoded target (:144-158), write_color (:160).
+__global__ void blend_tile_kernel(float4 *__restrict__ target, const float4 *__restrict__ planes, int nplanes, int width,
+                                  int tileX, int tileY, int tileW, int tileH, int pass, int spp_pass) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= tileW * tileH) return;
+    int ty = i / tileW;
+    size_t p = (size_t)(tileY + ty) * width + (tileX + (i - ty * tileW));
+    size_t stride = (size_t)tileW * tileH;
+    V4 acc = v4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int k = 0; k < nplanes; ++k) {
+        float4 v = planes[(size_t)k * stride + i];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float n = (float)spp_pass;
+    V4 passAcc = v4(acc.x / n, acc.y / n, acc.z / n, acc.w / n);
+    V4 finalColor;
+    if (pass == 0) {
+        finalColor = passAcc;
+    } else {
+        float4 e = target[p];
+        float ex = e.x * e.x, ey = e.y * e.y, ez = e.z * e.z;
+        float totalRaysSoFar = (float)(pass * spp_pass + spp_pass);
+        float passWeight = n / totalRaysSoFar;
+        finalColor.x = ex * (1.0f - passWeight) + passAcc.x * passWeight;
+        finalColor.y = ey * (1.0f - passWeight) + passAcc.y * passWeight;
+        finalColor.z = ez * (1.0f - passWeight) + passAcc.z * passWeight;
+        finalColor.w = 1.0f;
+    }
+    V4 w = write_color(finalColor);
+    target[p] = make_float4(w.x, w.y, w.z, w.w);
+}
+
 // target[p] = write_color(accum[p] / spp)   (Shaders.metal:142, 150, 160)
 __global__ void resolve_kernel(float4 *__restrict__ target, const float4 *__restrict__ accum, int npix, float spp) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -82,6 +116,15 @@ hipError_t launch_fold(float4 *accum, const float4 *planes, int nplanes, int wid
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(fold_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, accum, planes, nplanes, width, height,
                        tileX, tileY, tileW, tileH);
+    return hipGetLastError();
+}
+
+hipError_t launch_blend_tile(float4 *target, const float4 *planes, int nplanes, int width, int tileX, int tileY, int tileW,
+                             int tileH, int pass, int spp_pass, hipStream_t stream) {
+    int n = tileW * tileH;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(blend_tile_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, target, planes, nplanes, width, tileX,
+                       tileY, tileW, tileH, pass, spp_pass);
     return hipGetLastError();
 }
 

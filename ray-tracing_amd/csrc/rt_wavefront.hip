@@ -89,7 +89,8 @@ RT_DEV void store_item(const TraceParams &Pc, uint32_t px, uint32_t py, uint32_t
     const TraceParams *C = &Pc;
     size_t p = (size_t)py * C->width + px;
     if (C->mode == kModeAccum) {
-        C->planes[(size_t)chunk * ((size_t)C->width * C->height) + p] = acc;
+        const size_t q = (size_t)(py - (uint32_t)C->plane_y0) * (uint32_t)C->plane_w + (px - (uint32_t)C->plane_x0);
+        C->planes[(size_t)chunk * C->plane_stride + q] = acc;
     } else {
         // Shaders.metal:142-160
         float n = (float)C->spp_pass;

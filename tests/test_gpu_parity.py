@@ -558,6 +558,38 @@ def test_degenerate_inputs(rt, oracle, renderer):
     assert np.array_equal(bits(img), bits(oracle.image(u, objs2, w, h)))
 
 
+def test_contexts_give_their_device_memory_back(rt):
+    """setupMetal / teardown in a loop (ContentView.swift:328-356 runs once per app; a host that re-creates renderers must
+    not leak): every buffer a context allocated -- target, accumulation, planes, queues, scene in all its forms, the
+    tiled kind's tiles, staging -- is freed by rt_destroy, so free device memory is the same after every round."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+
+    def free_bytes():
+        free, total = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
+
+    seen = []
+    for rep in range(4):
+        r = rt.MetalRenderer(device=0)
+        try:
+            for name, kw in (("cover", {}), ("random_spheres", {"n": 3000}), ("cornell", {})):
+                objs, n = rt.scene(name, **kw)
+                w, h = 96, 54
+                u = rt.config_uniforms(name, w, h, 2, 8, n)
+                r.setupTexture(w, h)
+                r.renderImage(u, objs, n)
+                r.firstHit(u, objs, n)
+                r.present(w, h)
+                u.tileWidth, u.tileHeight = 64, 54
+                assert r._lib.rt_render_tile(r._ctx, C.byref(u), objs, n) in (0, 1)
+        finally:
+            r.close()
+        seen.append(free_bytes())
+    assert seen[1] == seen[2] == seen[3], seen  # (the first round also pays for HIP's own one-time allocations)
+
+
 def test_error_codes(rt):
     r = rt.MetalRenderer(0)
     objs, n = rt.scene("three_spheres")

@@ -4,7 +4,7 @@
 set -u
 OUT=$1; shift
 mkdir -p "$OUT"
-ARGS=${@:-"--steps 2 --warmup 1 --no-cpu-baseline"}
+ARGS=${@:-"--steps 2 --warmup 1 --no-cpu-baseline --valu-steps 0"}
 export TMPDIR=/tmp
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o run --output-format csv -- python3 bench.py $ARGS > "$OUT/stats.log" 2>&1 || { tail -5 "$OUT/stats.log"; exit 1; }
 pass() {
@@ -16,4 +16,6 @@ pass pmc_lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_INS
 pass pmc_fetch FETCH_SIZE
 pass pmc_write WRITE_SIZE
 pass pmc_mfma SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_SMEM SQ_INSTS_VMEM
+# cycles in which vector and matrix instructions execute together (its own pass: the name is not in every ROCm release)
+timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES -d "$OUT/pmc_coexec" -o run --output-format csv -- python3 bench.py $ARGS > "$OUT/pmc_coexec.log" 2>&1 || echo "pass pmc_coexec failed (counter names?)"
 echo done
