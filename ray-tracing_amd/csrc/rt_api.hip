@@ -593,7 +593,9 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P, bool noalloc = false) {
     }
     if (ctx->opt_blocks_per_cu > 0) per_cu = ctx->opt_blocks_per_cu;
     long long blocks = (long long)per_cu * ctx->num_cus;
-    long long need = ((long long)P.nitems + threads - 1) / threads;
+    // no more workgroups than there are waves' worth of items (a wave draws 64 at a time); small launches -- one 64 x 64
+    // tile of the reference's progressive flow -- are spread over the compute units rather than packed into few
+    long long need = ((long long)P.nitems + 63) / 64;
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
     uint32_t *counters = ctx->counters;
