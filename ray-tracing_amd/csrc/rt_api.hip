@@ -65,6 +65,7 @@ struct rt_ctx {
     DevBuf<float4> tiles, tile_frames;  // tiled matrix-core kind (TraceParams::tiles)
     DevBuf<int> tile_obj;
     int ntiles = 0;
+    bool scene_dense = false;  // lines through the scene cross many spheres (dense_scene): kernels with the lane-by-lane exact pass
     bool tiles_ok = false;     // all but a few spheres can be filtered in their tile (the others go to the exact test for every ray)
     LiftFrame lift = {0.0f, 0.0f, 0.0f, 1.0f};
     float oo_limit_m = -1.0f;  // origin limit of the matrix-core filter in the lifted frame; < 0: scene not eligible
@@ -342,6 +343,47 @@ TileSet build_tiles(const std::vector<float4> &sph, const std::vector<int> &sph_
 
 // Object[] (160-byte AoS records) -> compact device arrays.  Sphere slots keep the objects' relative order;
 // the slot count is padded to a multiple of 32 with records that can never be hit.
+// Do lines through the scene cross many spheres?  128 lines through pseudo-random points of the box of the sphere
+// centres, in pseudo-random directions, are tested against every sphere (the sphere filter tests lines, not rays); the
+// scene counts as dense when they cross kDenseMeanSpheres or more on average: nested glass shells about 170, the cover
+// scene 3.  Such scenes get the kernels that carry the lane-by-lane form of the exact pass (rt_hit.hpp).
+constexpr double kDenseMeanSpheres = 24.0;
+bool dense_scene(const std::vector<float4> &sph) {
+    const size_t n = sph.size();
+    if (n < 32) return false;
+    // box of the centres without the outermost 2 % per axis (a ground sphere of radius 1000 must not set the scale)
+    double lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        std::vector<float> v(n);
+        for (size_t i = 0; i < n; ++i) v[i] = a == 0 ? sph[i].x : a == 1 ? sph[i].y : sph[i].z;
+        std::sort(v.begin(), v.end());
+        lo[a] = v[n / 50];
+        hi[a] = v[n - 1 - n / 50];
+    }
+    uint32_t st = 0x9e3779b9u;
+    auto rnd = [&]() -> double {  // [0, 1)
+        st = st * 747796405u + 2891336453u;
+        uint32_t w = ((st >> ((st >> 28u) + 4u)) ^ st) * 277803737u;
+        return (double)((w >> 22u) ^ w) * (1.0 / 4294967296.0);
+    };
+    const int lines = 128;
+    size_t crossed = 0;
+    for (int l = 0; l < lines; ++l) {
+        double o[3], d[3], dd;
+        for (int a = 0; a < 3; ++a) o[a] = lo[a] + (hi[a] - lo[a]) * rnd();
+        do {
+            for (int a = 0; a < 3; ++a) d[a] = 2.0 * rnd() - 1.0;
+            dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        } while (dd > 1.0 || dd < 1e-4);
+        for (size_t i = 0; i < n; ++i) {
+            const double cx = o[0] - sph[i].x, cy = o[1] - sph[i].y, cz = o[2] - sph[i].z, r = sph[i].w;
+            const double b = cx * d[0] + cy * d[1] + cz * d[2];
+            if (b * b - dd * (cx * cx + cy * cy + cz * cz - r * r) >= 0.0) ++crossed;  // NaN compares false
+        }
+    }
+    return (double)crossed >= kDenseMeanSpheres * lines;
+}
+
 int upload_scene(rt_ctx *ctx, const Object *objs, int n) {
     if (n < 0 || (n > 0 && !objs)) return fail(ctx, RT_ERR_INVALID, "rt: bad object array");
     // The reference re-sends its objects with every dispatch (ContentView.swift:689-696), and so may callers of
@@ -493,6 +535,7 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n) {
     ctx->matrix_outliers = outliers;
     ctx->ntiles = tileset.ntiles;
     ctx->tiles_ok = tileset.ok;
+    ctx->scene_dense = dense_scene(sph);
     ctx->nquad = (int)quads.size();
     ctx->nobj = n;
     ctx->uploaded.assign((const unsigned char *)objs, (const unsigned char *)objs + nbytes);
@@ -546,6 +589,7 @@ void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
     P.lift = ctx->lift;
     P.nobj = ctx->nobj;
     P.resolve_mode = ctx->opt_resolve;
+    P.dense_kernel = ctx->opt_resolve == 2 || (ctx->opt_resolve == 0 && ctx->scene_dense) ? 1 : 0;
     P.width = ctx->width;
     P.height = ctx->height;
     P.pass = u->currentSample;

@@ -601,7 +601,7 @@ RT_DEV void resolve_balanced(const F &f, uint32_t *wave_masks, uint32_t nz, int 
 struct LaneBest {
     float t;        // smallest accepted root so far (tbest on entry)
     uint32_t slot;  // its slot, 0xFFFFFFFF while none
-    float n;        // its numerator (root * a up to rounding), +inf while none
+    float n;        // its numerator (root * a up to rounding); +inf while none was found in this call
 };
 struct LaneRoot {
     bool ok, retry;  // retry: the first root exists but is not above kTMin, so the second has to be looked at
@@ -683,7 +683,12 @@ RT_DEV void resolve_word_per_lane(const F &f, uint32_t m, int base, V3 o, V3 d, 
 // the pooled form.  all = true: every word per lane.
 template <typename F, bool PROF>
 RT_DEV uint32_t resolve_dense_words(const F &f, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, V3 o, V3 d, const RootDiv &dv,
-                                    bool all, LaneBest &best, Prof<PROF> &prof) {
+                                    bool all, Prof<PROF> &prof) {
+    // the lane's closest (distance, slot) so far lives in LDS beside the pooled form's minima (closest_sphere); it is
+    // held in registers only here, so that the sphere filter does not carry it
+    unsigned long long *best_lds = (unsigned long long *)(wave_masks + kBestOffset);
+    const unsigned long long b0 = best_lds[lane];
+    LaneBest best = {__uint_as_float((uint32_t)(b0 >> 32)), (uint32_t)b0, __builtin_inff()};
     // words that are non-empty in some lane (wave-uniform)
     uint32_t any = nz;
 #pragma unroll
@@ -699,6 +704,7 @@ RT_DEV uint32_t resolve_dense_words(const F &f, uint32_t *wave_masks, uint32_t n
             nz &= ~(1u << w);
         }
     }
+    best_lds[lane] = ((unsigned long long)__float_as_uint(best.t) << 32) | best.slot;
     return nz;
 }
 
@@ -720,7 +726,7 @@ RT_DEV uint32_t resolve_dense_words(const F &f, uint32_t *wave_masks, uint32_t n
 // The bounds assume operands in the normal float range with magnitudes below 2^60.  A NaN or infinity in q has
 // an unspecified sign bit; that is harmless because such operands cannot produce a finite root in pass B's
 // arithmetic either.
-template <typename F, bool PROF>
+template <typename F, bool PROF, bool DENSE>
 RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool active, V3 o, V3 d, float &tbest,
                           Prof<PROF> &prof, Work &work) {
     const float a = dot(d, d);
@@ -740,7 +746,6 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
     // every lane's closest (distance, slot) so far, kept in LDS where other lanes can lower it (resolve_balanced)
     unsigned long long *best = (unsigned long long *)(wave_masks + kBestOffset);
     best[lane] = ((unsigned long long)__float_as_uint(tbest) << 32) | 0xFFFFFFFFull;
-    LaneBest lane_best = {tbest, 0xFFFFFFFFu, __builtin_inff()};
     f.start(general);
     for (int g0 = 0; g0 < P.ngroups; g0 += kRoundWords * kWordGroups) {
         const int g1 = min(P.ngroups, g0 + kRoundWords * kWordGroups);
@@ -771,30 +776,31 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
         prof.lap(1);
         // Which form of pass B: pooled over the wave (the usual case: a couple of candidates per ray, a few lanes with
         // more), except for words of 32 spheres in which most lanes hold many candidates (nested shells): those go lane
-        // by lane.  Looking for such words costs a pass over the words, so it is only done when a quarter of the lanes
-        // have three or more non-empty words and the first of them is dense; and a wave that found no such round asks
-        // again only on every eighth of its searches.  (A wave with a ray whose a = d.d is out of the range of the
-        // shared-reciprocal division stays pooled.)
-        if (P.resolve_mode != 1 && !dv.slow) {
-            bool look = P.resolve_mode == 2;
-            if (!look && (work.dense || (work.trips & 7u) == 0u)) {
-                if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(__builtin_popcount(nz) >= 3)) >= 16) {
-                    const uint32_t first = nz ? wave_masks[__builtin_ctz(nz) * 64 + lane] : 0u;
-                    look = __builtin_popcountll(__builtin_amdgcn_ballot_w64(__builtin_popcount(first) >= kDenseWordBits)) >= 16;
+        // by lane.  That code is only part of the kernels launched for scenes in which rays cross many spheres (DENSE;
+        // the host decides at scene upload), so that the usual kernels do not pay for it in registers.  Looking for
+        // dense words costs a pass over the words, so it is only done when a quarter of the lanes have three or more
+        // non-empty words and the first of them is dense; and a wave that found no such round asks again only on every
+        // eighth of its searches.  (A wave with a ray whose a = d.d is out of the range of the shared-reciprocal
+        // division stays pooled.)
+        if constexpr (DENSE) {
+            if (P.resolve_mode != 1 && !dv.slow) {
+                bool look = P.resolve_mode == 2;
+                if (!look && (work.dense || (work.trips & 7u) == 0u)) {
+                    if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(__builtin_popcount(nz) >= 3)) >= 16) {
+                        const uint32_t first = nz ? wave_masks[__builtin_ctz(nz) * 64 + lane] : 0u;
+                        look = __builtin_popcountll(__builtin_amdgcn_ballot_w64(__builtin_popcount(first) >= kDenseWordBits)) >= 16;
+                    }
+                    work.dense = look;
                 }
-                work.dense = look;
+                if (look) nz = resolve_dense_words(f, wave_masks, nz, 4 * g0, lane, o, d, dv, P.resolve_mode == 2, prof);
             }
-            if (look) nz = resolve_dense_words(f, wave_masks, nz, 4 * g0, lane, o, d, dv, P.resolve_mode == 2, lane_best, prof);
         }
         resolve_balanced(f, wave_masks, nz, 4 * g0, lane, o, d, dv, prof);
         prof.lap(2);
     }
-    // the answer is the smaller of what the two forms found (equal distances: the lower slot)
     const unsigned long long r = best[lane];
-    const unsigned long long r2 = ((unsigned long long)__float_as_uint(lane_best.t) << 32) | lane_best.slot;
-    const unsigned long long rr = r2 < r ? r2 : r;
-    tbest = __uint_as_float((uint32_t)(rr >> 32));
-    return (int)(uint32_t)rr;  // 0xFFFFFFFF = -1: no hit
+    tbest = __uint_as_float((uint32_t)(r >> 32));
+    return (int)(uint32_t)r;  // 0xFFFFFFFF = -1: no hit
 }
 
 // Asynchronous copy of tile t (count spheres) into LDS buffer b: every wave of the workgroup copies 1 KiB pieces,
@@ -904,7 +910,7 @@ RT_DEV int closest_sphere_tiled(const TraceParams &P, Fetch<kFetchTiled> &f, uin
 }
 
 // Closest hit over spheres and quads; fills hit and returns the object index or -1.
-template <typename F, bool PROF>
+template <typename F, bool PROF, bool DENSE = false>
 RT_DEV int world_hit(const TraceParams &P, F &f, uint32_t *wave_masks, bool active, V3 o, V3 d, Hit &hit, float &t_out,
                      Prof<PROF> &prof, Work &work) {
     float tbest = kMaxFloat;
@@ -913,7 +919,7 @@ RT_DEV int world_hit(const TraceParams &P, F &f, uint32_t *wave_masks, bool acti
     if constexpr (F::kTiled) {
         slot = closest_sphere_tiled(P, f, wave_masks, active, o, d, tbest, prof, work);
     } else {
-        slot = closest_sphere(P, f, wave_masks, active, o, d, tbest, prof, work);
+        slot = closest_sphere<F, PROF, DENSE>(P, f, wave_masks, active, o, d, tbest, prof, work);
     }
     int obj = -1;
     if (slot >= 0) {

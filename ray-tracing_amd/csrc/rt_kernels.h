@@ -47,7 +47,9 @@ struct TraceParams {
     int stage_mats;         // matrix-core kind: sph_obj and mats are staged in LDS too (the launch reserved the room)
     int nobj;               // objects (length of mats)
     int resolve_mode;       // exact pass over the candidates: 0 chosen per wave and round, 1 always pooled over the wave,
-                            // 2 always per lane (rt_hit.hpp closest_sphere)
+                            // 2 always per lane (rt_hit.hpp closest_sphere) ...
+    int dense_kernel;       // ... in the kernel instantiation that carries the per-lane form (launch_trace picks it when
+                            // this is set: scenes whose rays cross many spheres, or resolve_mode 2)
     float4 *rayq;           // per-wave queues of generated camera rays: grid lanes x kQueueRays x 2 float4
     int maxDepth;           // Uniforms.maxRayDepth
     V4 sky;                 // Uniforms.globalIllumation
