@@ -80,8 +80,9 @@ enum {
                                even drain gains) */
     RT_OPT_TAIL_SAMPLES = 9, /* samples per pixel in that tail; -1 (default) = automatic */
     RT_OPT_RESOLVE = 10     /* how the exact hit test walks the candidates the sphere filter left (LDS-staged scenes;
-                               results are identical): 0 = chosen per wave (default), 1 = always pooled over the wave,
-                               2 = always lane by lane, two candidates in flight */
+                               results are identical): 0 = automatic (default): pooled over the wave, and for scenes
+                               whose lines cross many spheres (nested shells; decided at scene upload) dense candidate
+                               words lane by lane, four candidates in flight; 1 = always pooled; 2 = always lane by lane */
 };
 
 /* setupMetal (ContentView.swift:328-356): device, queue, pipelines.  `device` is the HIP device ordinal.
