@@ -63,6 +63,7 @@ struct rt_ctx {
     DevBuf<float4> sph, sphc;
     DevBuf<_Float16> sphm;  // matrix-core filter: lifted A operands (rt_lift.hpp)
     DevBuf<float4> tiles, tile_frames;  // tiled matrix-core kind (TraceParams::tiles)
+    DevBuf<float4> word_bounds;         // balls around and inside every 32 sphere slots (TraceParams::word_bounds)
     DevBuf<int> tile_obj;
     int ntiles = 0;
     bool scene_dense = false;  // lines through the scene cross many spheres (dense_scene): kernels with the lane-by-lane exact pass
@@ -348,17 +349,21 @@ TileSet build_tiles(const std::vector<float4> &sph, const std::vector<int> &sph_
 // scene counts as dense when they cross kDenseMeanSpheres or more on average: nested glass shells about 170, the cover
 // scene 3.  Such scenes get the kernels that carry the lane-by-lane form of the exact pass (rt_hit.hpp).
 constexpr double kDenseMeanSpheres = 24.0;
-bool dense_scene(const std::vector<float4> &sph) {
-    const size_t n = sph.size();
+bool dense_scene(const std::vector<float4> &sph, int nsph) {  // the first nsph records (the rest is padding)
+    const size_t n = (size_t)nsph;
     if (n < 32) return false;
     // box of the centres without the outermost 2 % per axis (a ground sphere of radius 1000 must not set the scale)
     double lo[3], hi[3];
     for (int a = 0; a < 3; ++a) {
-        std::vector<float> v(n);
-        for (size_t i = 0; i < n; ++i) v[i] = a == 0 ? sph[i].x : a == 1 ? sph[i].y : sph[i].z;
+        std::vector<float> v;
+        for (size_t i = 0; i < n; ++i) {
+            const float c = a == 0 ? sph[i].x : a == 1 ? sph[i].y : sph[i].z;
+            if (std::isfinite(c)) v.push_back(c);  // (a value that is not a number has no place in an order)
+        }
+        if (v.empty()) return false;
         std::sort(v.begin(), v.end());
-        lo[a] = v[n / 50];
-        hi[a] = v[n - 1 - n / 50];
+        lo[a] = v[v.size() / 50];
+        hi[a] = v[v.size() - 1 - v.size() / 50];
     }
     uint32_t st = 0x9e3779b9u;
     auto rnd = [&]() -> double {  // [0, 1)
@@ -382,6 +387,80 @@ bool dense_scene(const std::vector<float4> &sph) {
         }
     }
     return (double)crossed >= kDenseMeanSpheres * lines;
+}
+
+// Bounding balls of consecutive sphere slots, for the kernels that prune candidates a group at a time (rt_hit.hpp
+// cull_words, cull_granules).  Per group -- a word of 32 slots, and each of its four granules of 8 -- two balls about
+// one centre C (the component-wise median of the group's centres, rounded to float): an outer ball (C, Rout) that
+// holds every sphere of the group and an inner ball (C, Rin) that every sphere of the group holds.  Spheres that
+// would blow the outer ball up (|c - C| + r above four times the group's median of that number: a ground sphere
+// among small ones) are left out of both balls and listed in a mask of exempt slots, which a prune of the group
+// leaves standing.  Stored squared and with the margins the kernel's argument needs: R2out = Rout^2 (1 + 2^-6)
+// rounded up, R2in = Rin^2 (1 - 2^-6) rounded down, and no inner ball (R2in = -1) unless Rin > 0 and the largest radius
+// of the group is at most 64 Rin.  A group with a sphere that is not finite, or without spheres, gets R2out = +inf
+// and R2in = -1: never pruned.  Layout: kBoundVec4 float4 per word: (C, R2out), (R2in, exempt mask bits, 0, 0) of the
+// word, then the same pair for each granule (mask bit of slot p of the word: 0x80000000 >> p).
+void group_bounds(const std::vector<float4> &sph, int i0, int i1, int word0, float4 *out) {
+    const float inf = std::numeric_limits<float>::infinity();
+    out[0] = make_float4(0.0f, 0.0f, 0.0f, inf);
+    out[1] = make_float4(-1.0f, 0.0f, 0.0f, 0.0f);
+    if (i1 <= i0) return;
+    const int n = i1 - i0;
+    std::vector<float> v[3];
+    for (int i = i0; i < i1; ++i) {
+        const float4 &q = sph[(size_t)i];
+        if (!(std::isfinite(q.x) && std::isfinite(q.y) && std::isfinite(q.z) && std::isfinite(q.w))) return;
+        v[0].push_back(q.x); v[1].push_back(q.y); v[2].push_back(q.z);
+    }
+    float c[3];
+    for (int a = 0; a < 3; ++a) {
+        std::nth_element(v[a].begin(), v[a].begin() + n / 2, v[a].end());
+        c[a] = v[a][(size_t)(n / 2)];
+    }
+    std::vector<double> dist((size_t)n), reach((size_t)n);
+    for (int i = i0; i < i1; ++i) {
+        const float4 &q = sph[(size_t)i];
+        const double dx = (double)q.x - c[0], dy = (double)q.y - c[1], dz = (double)q.z - c[2];
+        dist[(size_t)(i - i0)] = std::sqrt(dx * dx + dy * dy + dz * dz) * (1.0 + 0x1p-40);
+        reach[(size_t)(i - i0)] = dist[(size_t)(i - i0)] + std::fabs((double)q.w);
+    }
+    std::vector<double> sorted = reach;
+    std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
+    const double limit = 4.0 * sorted[(size_t)(n / 2)];
+    double rout = 0.0, rin = std::numeric_limits<double>::infinity(), rmax = 0.0;
+    uint32_t exempt = 0;
+    for (int i = i0; i < i1; ++i) {
+        const double r = std::fabs((double)sph[(size_t)i].w);
+        if (reach[(size_t)(i - i0)] > limit) {
+            exempt |= 0x80000000u >> (i - word0);
+            continue;
+        }
+        rout = std::max(rout, reach[(size_t)(i - i0)]);
+        rin = std::min(rin, r - dist[(size_t)(i - i0)]);
+        rmax = std::max(rmax, r);
+    }
+    const double r2o = rout * rout * (1.0 + 0x1p-6);
+    float fo = (float)r2o;
+    if ((double)fo < r2o) fo = std::nextafterf(fo, inf);
+    out[0] = make_float4(c[0], c[1], c[2], fo);
+    std::memcpy(&out[1].y, &exempt, sizeof exempt);
+    if (rin > 0.0 && rmax <= 64.0 * rin) {
+        const double r2i = rin * rin * (1.0 - 0x1p-6);
+        float fi = (float)r2i;
+        if ((double)fi > r2i) fi = std::nextafterf(fi, -inf);
+        out[1].x = fi;
+    }
+}
+std::vector<float4> word_bounds(const std::vector<float4> &sph, int nsph) {
+    const size_t nwords = (sph.size() + 31) / 32;
+    std::vector<float4> out((size_t)kBoundVec4 * nwords);
+    for (size_t w = 0; w < nwords; ++w) {
+        const int i0 = (int)w * 32;
+        float4 *rec = out.data() + (size_t)kBoundVec4 * w;
+        group_bounds(sph, i0, std::min(nsph, i0 + 32), i0, rec);
+        for (int g = 0; g < 4; ++g) group_bounds(sph, std::min(nsph, i0 + 8 * g), std::min(nsph, i0 + 8 * g + 8), i0, rec + 2 + 2 * g);
+    }
+    return out;
 }
 
 int upload_scene(rt_ctx *ctx, const Object *objs, int n) {
@@ -521,6 +600,7 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n) {
     RT_TRY(upload(ctx, ctx->sphm, sphm));
     RT_TRY(upload(ctx, ctx->tiles, tileset.tiles));
     RT_TRY(upload(ctx, ctx->tile_frames, tileset.frames));
+    RT_TRY(upload(ctx, ctx->word_bounds, word_bounds(sph, nsph)));
     RT_TRY(upload(ctx, ctx->tile_obj, tileset.obj));
     RT_TRY(upload(ctx, ctx->sph_obj, sph_obj));
     RT_TRY(upload(ctx, ctx->quads, quads));
@@ -535,7 +615,7 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n) {
     ctx->matrix_outliers = outliers;
     ctx->ntiles = tileset.ntiles;
     ctx->tiles_ok = tileset.ok;
-    ctx->scene_dense = dense_scene(sph);
+    ctx->scene_dense = dense_scene(sph, nsph);
     ctx->nquad = (int)quads.size();
     ctx->nobj = n;
     ctx->uploaded.assign((const unsigned char *)objs, (const unsigned char *)objs + nbytes);
@@ -584,6 +664,7 @@ void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
     P.sphm = ctx->sphm.ptr;
     P.tiles = ctx->tiles.ptr;
     P.tile_frames = ctx->tile_frames.ptr;
+    P.word_bounds = ctx->word_bounds.ptr;
     P.tile_obj = ctx->tile_obj.ptr;
     P.ntiles = ctx->ntiles;
     P.lift = ctx->lift;
@@ -748,6 +829,7 @@ RT_API void rt_destroy(rt_ctx *ctx) {
     (void)hipFree(ctx->sphm.ptr);
     (void)hipFree(ctx->tiles.ptr);
     (void)hipFree(ctx->tile_frames.ptr);
+    (void)hipFree(ctx->word_bounds.ptr);
     (void)hipFree(ctx->tile_obj.ptr);
     (void)hipFree(ctx->sph_obj.ptr);
     (void)hipFree(ctx->quads.ptr);

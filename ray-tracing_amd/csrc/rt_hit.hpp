@@ -224,6 +224,8 @@ struct Prof {
 struct Work {
     uint32_t trips = 0, blocks = 0;
     bool dense = false;  // the wave's last closest-hit search had dense candidate words (closest_sphere)
+    int last_slot = 0;   // per lane (the only member that is): the sphere slot this lane's path hit last (dense rounds
+                         // resolve the candidates next to it first)
 };
 
 // Per-ray constants of the two filters.
@@ -679,22 +681,229 @@ RT_DEV void resolve_word_per_lane(const F &f, uint32_t m, int base, V3 o, V3 d, 
     }
 }
 
-// The words of a round that are dense in most lanes are resolved per lane and struck from nz; the others are left to
-// the pooled form.  all = true: every word per lane.
-template <typename F, bool PROF>
-RT_DEV uint32_t resolve_dense_words(const F &f, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, V3 o, V3 d, const RootDiv &dv,
-                                    bool all, Prof<PROF> &prof) {
-    // the lane's closest (distance, slot) so far lives in LDS beside the pooled form's minima (closest_sphere); it is
-    // held in registers only here, so that the sphere filter does not carry it
-    unsigned long long *best_lds = (unsigned long long *)(wave_masks + kBestOffset);
-    const unsigned long long b0 = best_lds[lane];
-    LaneBest best = {__uint_as_float((uint32_t)(b0 >> 32)), (uint32_t)b0, __builtin_inff()};
-    // words that are non-empty in some lane (wave-uniform)
+// Prune of candidates that cannot win against the lane's best accepted root t so far.  With u = o - c, the function
+// g(s) = |u + s d|^2 - r^2 = a s^2 + 2 (u.d) s + (|u|^2 - r^2) is convex and its zeros are the sphere's roots, so the
+// sphere has no root in [0, t] -- and therefore no root the reference would accept that is not above t -- when
+//   g(0) < 0 and g(t) < 0 (o and P = o + t d inside: the only positive root is the exit, beyond P), or
+//   g(0) > 0 and u.d > 0 (o outside, centre behind o: both roots negative), or
+//   g(0) > 0, g(t) > 0 and u.d + t a < 0 (o and P outside, closest approach beyond P: the ray enters beyond P).
+// The same three tests prune a whole word of 32 spheres when "inside" is taken against a ball that every sphere of
+// the word contains and "outside" against a ball that contains them all (TraceParams::word_bounds).
+// Every comparison is made with a margin M = m X + 2^-21 |o|^2, X = |u|^2 + 2 t |u.d| + t^2 a >= max(|u|^2,
+// |P - c|^2), that is far above the rounding of g (2^-21 X) and keeps the true roots away from [0, t] by more than
+// the reference's computed root can be off.  One sphere: m = 2^-15 and the radius^2 is widened by 2^-10 either way;
+// then |g(t)| > M puts the exit 2^-11 r / |d| beyond t (the reference's exit root is within 2^-21 r / |d|) and a
+// grazing entry 2^-8.8 sqrt(X) / |d| beyond t (the reference's first root of a near-zero discriminant is within
+// 2^-10.2 sqrt(X) / |d|; away from grazing both bounds grow apart); in the second case the reference's numerators
+// are not positive whatever the rounding, given the signs of its b and c.  A word: m = 2^-8 and the balls are
+// widened by 2^-6, which keeps every root of every sphere of the word 2^-9 sqrt(X) / |d| outside [0, t].  The signs of
+// u.d and u.d + t a are taken only when clear of their rounding (2^-19 and 2^-18 of |u||d|, sqrt(X)|d|).  NaN or
+// infinite operands pass no comparison.  has_t = false (no accepted root yet): only the second case applies.
+struct PruneRay {
+    V3 o, d;
+    float k1, a, a38, a36, t, t2, t2a;  // 2^-21 |o|^2, d.d, 2^-38 a, 2^-36 a, best root t, 2 t, t^2 a
+    bool has_t;
+};
+RT_DEV bool no_root_up_to_t(float cx, float cy, float cz, float r2in, float r2out, float m, const PruneRay &y) {
+    const float ux = y.o.x - cx, uy = y.o.y - cy, uz = y.o.z - cz;
+    const float so = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+    const float bf = __builtin_fmaf(uz, y.d.z, __builtin_fmaf(uy, y.d.y, ux * y.d.x));
+    const float pd = __builtin_fmaf(y.t, y.a, bf);      // (P - c).d
+    const float sp = __builtin_fmaf(y.t, pd + bf, so);  // |P - c|^2
+    const float X = __builtin_fmaf(y.t2, __builtin_fabsf(bf), so + y.t2a);
+    const float M = __builtin_fmaf(m, X, y.k1);
+    const bool neg = (so + M < r2in) & (sp + M < r2in);
+    const bool pos0 = so - M > r2out, post = sp - M > r2out;
+    const bool behind = (bf > 0.0f) & (bf * bf > so * y.a38);
+    const bool ahead = (pd < 0.0f) & (pd * pd > X * y.a36);
+    return (pos0 & behind) | (y.has_t & (neg | (pos0 & post & ahead)));
+}
+RT_DEV bool cannot_win(f4v rec, const PruneRay &y) {
+    const float r2 = rec.w * rec.w;
+    return no_root_up_to_t(rec.x, rec.y, rec.z, __builtin_fmaf(-0x1p-10f, r2, r2), __builtin_fmaf(0x1p-10f, r2, r2), 0x1p-15f, y);
+}
+// Strikes the words whose 32 spheres cannot win as a whole (wave-uniform loop over the words that are non-empty in
+// some lane; the balls come through scalar loads).  Slots the word's balls leave out (exempt) stay.  Returns the
+// lane's remaining non-empty words.
+RT_DEV uint32_t cull_words(const float4 *word_bounds, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, const PruneRay &y) {
+    const const_f4_ptr balls = (const_f4_ptr)(uintptr_t)word_bounds + kBoundVec4 * (slot0 >> 5);
     uint32_t any = nz;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) any |= (uint32_t)__shfl_xor((int)any, off, 64);
     any = (uint32_t)__builtin_amdgcn_readfirstlane((int)any);
     while (any) {
+        const int w = __builtin_ctz(any);
+        any &= any - 1;
+        const f4v outer = balls[kBoundVec4 * w], inner = balls[kBoundVec4 * w + 1];
+        const uint32_t exempt = __float_as_uint(inner.y);  // wave-uniform
+        if (no_root_up_to_t(outer.x, outer.y, outer.z, inner.x, outer.w, 0x1p-8f, y) && ((nz >> w) & 1u)) {
+            uint32_t m = 0;
+            if (exempt) {
+                m = wave_masks[w * 64 + lane] & exempt;
+                wave_masks[w * 64 + lane] = m;
+            }
+            if (m == 0u) nz &= ~(1u << w);
+        }
+    }
+    return nz;
+}
+// The same a granule of 8 spheres at a time, every lane going through its own remaining words (the balls come
+// through vector loads: the words differ from lane to lane).
+RT_DEV uint32_t cull_granules(const float4 *word_bounds, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, const PruneRay &y) {
+    const float4 *balls = word_bounds + kBoundVec4 * (slot0 >> 5);
+    uint32_t todo = nz;
+    while (__builtin_amdgcn_ballot_w64(todo != 0u)) {
+        const bool live = todo != 0u;
+        const int w = live ? __builtin_ctz(todo) : 0;  // a lane that is through looks at the round's first word again
+        todo &= todo - 1;
+        const float4 *q = balls + kBoundVec4 * w + 2;
+        float4 b[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) b[k] = q[k];
+        uint32_t kill = 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const bool gone = no_root_up_to_t(b[2 * g].x, b[2 * g].y, b[2 * g].z, b[2 * g + 1].x, b[2 * g].w, 0x1p-8f, y);
+            kill |= gone ? (0xFF000000u >> (8 * g)) & ~__float_as_uint(b[2 * g + 1].y) : 0u;
+        }
+        if (live && kill) {
+            const uint32_t m = wave_masks[w * 64 + lane];
+            if (m & kill) {
+                wave_masks[w * 64 + lane] = m & ~kill;
+                if ((m & ~kill) == 0u) nz &= ~(1u << w);
+            }
+        }
+    }
+    return nz;
+}
+// Every lane walks its own candidate words (four candidates per turn, as resolve_word_per_lane takes them), strikes
+// what cannot win and writes the words back; returns the lane's non-empty words.
+template <typename F>
+RT_DEV uint32_t prune_candidates(const F &f, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, const PruneRay &y) {
+    uint32_t todo = nz, m = 0, word = 0, gone = 0;
+    int w = 0;
+    for (;;) {
+        if (m == 0) {
+            if (gone) {
+                word &= ~gone;
+                wave_masks[w * 64 + lane] = word;
+                if (word == 0u) nz &= ~(1u << w);
+                gone = 0;
+            }
+            if (todo) {
+                w = __builtin_ctz(todo);
+                todo &= todo - 1;
+                word = m = wave_masks[w * 64 + lane];
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(m != 0u) == 0) break;
+        // a lane that is through looks at the round's first sphere again and drops the answer
+        const bool live = m != 0u;
+        const uint32_t mm = live ? m : 1u;
+        const int p0 = __builtin_clz(mm), p3 = 31 - __builtin_ctz(mm);
+        const uint32_t m1 = mm & ~((0x80000000u >> p0) | (0x80000000u >> p3));
+        const int p1 = m1 ? __builtin_clz(m1) : p0, p2 = m1 ? 31 - __builtin_ctz(m1) : p3;
+        m = live ? m1 & ~((0x80000000u >> p1) | (0x80000000u >> p2)) : 0u;
+        const int base = live ? slot0 + w * 32 : slot0 - 31;
+        f4v c0 = f.load1(base + p0), c1 = f.load1(base + p1), c2 = f.load1(base + p2), c3 = f.load1(base + p3);
+        asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+        const bool g0 = cannot_win(c0, y), g1 = cannot_win(c1, y), g2 = cannot_win(c2, y), g3 = cannot_win(c3, y);
+        const uint32_t g = (g0 ? 0x80000000u >> p0 : 0u) | (g1 ? 0x80000000u >> p1 : 0u) | (g2 ? 0x80000000u >> p2 : 0u) | (g3 ? 0x80000000u >> p3 : 0u);
+        gone |= live ? g : 0u;
+    }
+    return nz;
+}
+
+// Dense rounds (most lanes hold many candidates: rays among nested shells collect every shell their line crosses).
+// (1) Probe: the four candidates next to the sphere the lane's path hit last (two at or before it in slot order, two
+// after it) are resolved exactly; among nested shells in radius order the next hit is one of them, elsewhere it is
+// merely a bound.  (2) With that bound whole words are struck (cull_words), then single candidates of the remaining
+// words (prune_candidates), and the survivors written back.  (3) Words
+// that are still dense in most lanes are resolved per lane and struck from nz, the others are left to the pooled
+// form.  all = true: every word per lane.
+template <typename F, bool PROF>
+RT_DEV uint32_t resolve_dense_words(const F &f, const float4 *word_bounds, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, V3 o,
+                                    V3 d, const RootDiv &dv, bool all, int hint, Prof<PROF> &prof) {
+    // the lane's closest (distance, slot) so far lives in LDS beside the pooled form's minima (closest_sphere); it is
+    // held in registers only here, so that the sphere filter does not carry it
+    unsigned long long *best_lds = (unsigned long long *)(wave_masks + kBestOffset);
+    const unsigned long long b0 = best_lds[lane];
+    LaneBest best = {__uint_as_float((uint32_t)(b0 >> 32)), (uint32_t)b0, __builtin_inff()};
+    {  // (1)
+        const int rel = min(max(hint - slot0, 0), 32 * kRoundWords - 1);
+        const int hw = rel >> 5, hp = rel & 31;
+        const uint32_t mh = (nz >> hw) & 1u ? wave_masks[hw * 64 + lane] : 0u;
+        const uint32_t upto = 0xFFFFFFFFu << (31 - hp);  // positions 0 .. hp
+        uint32_t below = mh & upto, above = mh & ~upto;
+        int wb = hw, wa = hw;
+        if (below == 0u) {  // nearest non-empty word before
+            const uint32_t nzb = nz & ((1u << hw) - 1u);
+            if (nzb) {
+                wb = 31 - __builtin_clz(nzb);
+                below = wave_masks[wb * 64 + lane];
+            }
+        }
+        if (above == 0u) {  // nearest non-empty word after
+            const uint32_t nza = hw < 31 ? nz & ~((2u << hw) - 1u) : 0u;
+            if (nza) {
+                wa = __builtin_ctz(nza);
+                above = wave_masks[wa * 64 + lane];
+            }
+        }
+        int k[4] = {-1, -1, -1, -1};
+        if (below) {
+            int q = 31 - __builtin_ctz(below);
+            k[0] = slot0 + wb * 32 + q;
+            below &= ~(0x80000000u >> q);
+            if (below) k[1] = slot0 + wb * 32 + 31 - __builtin_ctz(below);
+        }
+        if (above) {
+            int q = __builtin_clz(above);
+            k[2] = slot0 + wa * 32 + q;
+            above &= ~(0x80000000u >> q);
+            if (above) k[3] = slot0 + wa * 32 + __builtin_clz(above);
+        }
+        const int any_k = k[0] >= 0 ? k[0] : k[2];
+        const bool on = any_k >= 0;
+        const int s0 = k[0] >= 0 ? k[0] : (on ? any_k : slot0), s1 = k[1] >= 0 ? k[1] : s0, s2 = k[2] >= 0 ? k[2] : s0, s3 = k[3] >= 0 ? k[3] : s2;
+        f4v c0 = f.load1(s0), c1 = f.load1(s1), c2 = f.load1(s2), c3 = f.load1(s3);
+        asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+        const float nprune = on ? best.n : -__builtin_inff();  // a lane without candidates accepts nothing
+        const LaneRoot r0 = lane_root(c0, o, d, dv, nprune), r1 = lane_root(c1, o, d, dv, nprune);
+        const LaneRoot r2 = lane_root(c2, o, d, dv, nprune), r3 = lane_root(c3, o, d, dv, nprune);
+        lane_offer(best, r0, (uint32_t)s0);
+        lane_offer(best, r1, (uint32_t)s1);
+        lane_offer(best, r2, (uint32_t)s2);
+        lane_offer(best, r3, (uint32_t)s3);
+        if (__builtin_amdgcn_ballot_w64(on && (r0.retry || r1.retry || r2.retry || r3.retry))) {
+            if (on) {
+                lane_retry(best, r0, (uint32_t)s0, dv, nprune);
+                lane_retry(best, r1, (uint32_t)s1, dv, nprune);
+                lane_retry(best, r2, (uint32_t)s2, dv, nprune);
+                lane_retry(best, r3, (uint32_t)s3, dv, nprune);
+            }
+        }
+    }
+    PruneRay y;
+    y.o = o;
+    y.d = d;
+    y.k1 = 0x1p-21f * __builtin_fmaf(o.z, o.z, __builtin_fmaf(o.y, o.y, o.x * o.x));
+    y.a = dv.a;
+    y.a38 = 0x1p-38f * dv.a;
+    y.a36 = 0x1p-36f * dv.a;
+    y.has_t = best.slot != 0xFFFFFFFFu;
+    y.t = y.has_t ? best.t : 0.0f;
+    y.t2 = 2.0f * y.t;
+    y.t2a = y.t * y.t * y.a;
+    nz = cull_words(word_bounds, wave_masks, nz, slot0, lane, y);  // (2)
+    nz = cull_granules(word_bounds, wave_masks, nz, slot0, lane, y);
+    nz = prune_candidates(f, wave_masks, nz, slot0, lane, y);
+    // words that are non-empty in some lane (wave-uniform)
+    uint32_t any = nz;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) any |= (uint32_t)__shfl_xor((int)any, off, 64);
+    any = (uint32_t)__builtin_amdgcn_readfirstlane((int)any);
+    while (any) {  // (3)
         const int w = __builtin_ctz(any);
         any &= any - 1;
         const uint32_t m = (nz >> w) & 1u ? wave_masks[w * 64 + lane] : 0u;
@@ -792,7 +1001,7 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
                     }
                     work.dense = look;
                 }
-                if (look) nz = resolve_dense_words(f, wave_masks, nz, 4 * g0, lane, o, d, dv, P.resolve_mode == 2, prof);
+                if (look) nz = resolve_dense_words(f, P.word_bounds, wave_masks, nz, 4 * g0, lane, o, d, dv, P.resolve_mode == 2, work.last_slot, prof);
             }
         }
         resolve_balanced(f, wave_masks, nz, 4 * g0, lane, o, d, dv, prof);
@@ -800,6 +1009,9 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
     }
     const unsigned long long r = best[lane];
     tbest = __uint_as_float((uint32_t)(r >> 32));
+    if constexpr (DENSE) {
+        if ((uint32_t)r != 0xFFFFFFFFu) work.last_slot = (int)(uint32_t)r;
+    }
     return (int)(uint32_t)r;  // 0xFFFFFFFF = -1: no hit
 }
 

@@ -10,6 +10,7 @@
 namespace rt {
 
 enum { kModeAccum = 0, kModeProgressive = 1 };
+constexpr int kBoundVec4 = 10;  // float4 of bounding balls per word of 32 sphere slots (TraceParams::word_bounds)
 constexpr int kQueueRays = 64;  // camera rays per lane in the trace kernel's per-wave queue (two float4 each)
 
 // Tiled matrix-core kind (TraceParams::tiles, rt_hit.hpp closest_sphere_tiled).
@@ -50,6 +51,8 @@ struct TraceParams {
                             // 2 always per lane (rt_hit.hpp closest_sphere) ...
     int dense_kernel;       // ... in the kernel instantiation that carries the per-lane form (launch_trace picks it when
                             // this is set: scenes whose rays cross many spheres, or resolve_mode 2)
+    const float4 *word_bounds;  // kBoundVec4 float4 per word of 32 sphere slots: balls around and inside the word's spheres and
+                                // around and inside each of its four granules of 8 (rt_api.hip group_bounds)
     float4 *rayq;           // per-wave queues of generated camera rays: grid lanes x kQueueRays x 2 float4
     int maxDepth;           // Uniforms.maxRayDepth
     V4 sky;                 // Uniforms.globalIllumation

@@ -848,6 +848,85 @@ def test_exact_pass_forms_bit_exact(rt, oracle, renderer, name, w, h, spp, depth
         assert np.array_equal(bits(img), bits(want)), mode
 
 
+def _dense_scene(rt, kind):
+    """Scenes whose rays cross many spheres, built to stress the pruning of candidates by bounding balls and by single
+    tests: (objects, camera from, camera at)."""
+    rng = np.random.default_rng(11)
+    glass, air = rt.SwiftMaterial.dielectric(1.5), rt.SwiftMaterial.dielectric(1.0 / 1.5)
+    grey = rt.SwiftMaterial.lambertian(0.6, 0.6, 0.6)
+    objs = [rt.makeSphere((0.0, -100.5, -1.0), 100.0, rt.SwiftMaterial.lambertian(0.8, 0.8, 0.0))]
+    if kind == "drifting_shells":
+        # nested but not concentric, every shell internally tangent to the one around it at one point, every 25th
+        # sphere twice (equal distances: the lower slot must win), words of 32 not in radius order
+        shells = []
+        c, r = np.array([0.0, 0.0, -1.0]), 0.5
+        for k in range(220):
+            shells.append((c.copy(), r, glass if k % 2 == 0 else air))
+            if k % 25 == 7:
+                shells.append((c.copy(), r, grey))
+            shrink = 0.002
+            c = c + np.array([shrink, 0.0, 0.0])    # tangent at +x
+            r = r - shrink
+        order = np.arange(len(shells))
+        for b in range(0, len(order) - 16, 48):
+            rng.shuffle(order[b:b + 16])
+        for i in order:
+            objs.append(rt.makeSphere(tuple(float(v) for v in shells[i][0]), float(shells[i][1]), shells[i][2]))
+        return objs, (0.0, 0.25, 1.0), (0.0, 0.0, -1.0)
+    if kind == "clutter":
+        # overlapping spheres without any order, seen from just outside
+        mats = [glass, glass, rt.SwiftMaterial.metal(0.8, 0.8, 0.9, 0.05), rt.SwiftMaterial.lambertian(0.7, 0.3, 0.3)]
+        for i in range(300):
+            c = np.array([0.0, 0.3, -1.0]) + 1.5 * (rng.random(3) - 0.5)
+            objs.append(rt.makeSphere(tuple(float(v) for v in c), float(rng.uniform(0.15, 0.5)), mats[i % 4]))
+        return objs, (0.3, 0.5, 1.2), (0.0, 0.3, -1.0)
+    if kind == "far_shells":
+        # concentric shells far from the origin of the coordinates, seen from a distance
+        centre = np.array([1000.0, 500.0, -2000.0])
+        objs = [rt.makeSphere(tuple(centre + np.array([0.0, -5050.0, 0.0])), 5000.0, grey)]
+        for k in range(300):
+            objs.append(rt.makeSphere(tuple(float(v) for v in centre), 50.0 * (1.0 - k / 300.0), glass if k % 2 == 0 else air))
+        return objs, tuple(centre + np.array([0.0, 40.0, 300.0])), tuple(centre)
+    if kind == "shells_and_strays":
+        # shells with a sphere around everything, a sphere that is not a number and stray small spheres in between
+        objs.append(rt.makeSphere((0.0, 0.0, -1.0), 30.0, glass))
+        for k in range(260):
+            objs.append(rt.makeSphere((0.0, 0.0, -1.0), 0.5 * (1.0 - k / 260.0), glass if k % 2 == 0 else air))
+            if k % 37 == 5:
+                objs.append(rt.makeSphere((float("nan") if k == 5 else 0.3, 0.2, -0.7), 0.05, grey))
+            if k % 41 == 9:
+                objs.append(rt.makeSphere((0.0, 0.0, -1.0), 0.5 * (1.0 - k / 260.0), grey))   # coincides with a shell
+        return objs, (0.0, 0.25, 1.0), (0.0, 0.0, -1.0)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["drifting_shells", "clutter", "far_shells", "shells_and_strays"])
+def test_pruned_exact_pass_on_dense_scenes(rt, oracle, renderer, kind):
+    """Kernels for scenes whose rays cross many spheres strike candidates that cannot win before the exact pass (whole
+    words and granules by their bounding balls, single spheres by a test with margins).  Their images must have the
+    bits of the pooled exact pass, which resolves every candidate, and of the oracle."""
+    strict(renderer, rt)
+    objs, cam_from, cam_at = _dense_scene(rt, kind)
+    n = len(objs)
+    arr = rt.object_array(objs)
+    w, h, spp = 96, 54, 4
+    u = rt.config_uniforms("nested_glass", w, h, spp, 60, n)
+    f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+    rt.host_lib().rt_camera_setup(C.byref(u), f3(cam_from), f3(cam_at), f3([0, 1, 0]), 40.0, 0.0, 1.0, w, h)
+    renderer.setupTexture(w, h)
+    imgs = {}
+    for mode in (1, 2, 0):
+        renderer.set_option(rt.RT_OPT_RESOLVE, mode)
+        try:
+            imgs[mode] = renderer.renderImage(u, arr, n).copy()
+        finally:
+            renderer.set_option(rt.RT_OPT_RESOLVE, 0)
+    assert len(np.unique(bits(imgs[1]).reshape(-1, 4), axis=0)) > 50   # the camera really sees the spheres
+    assert np.array_equal(bits(imgs[2]), bits(imgs[1]))
+    assert np.array_equal(bits(imgs[0]), bits(imgs[1]))
+    assert np.array_equal(bits(imgs[1]), bits(oracle.image(u, arr, w, h)))
+
+
 @pytest.mark.parametrize("name,w,h,spp,depth,slots", [("cornell", 120, 96, 8, 10, 1 << 20), ("nested_glass", 96, 54, 4, 100, 2048),
                                                        ("three_spheres", 400, 225, 20, 50, 4096)])
 def test_wavefront_kernels_bit_exact(rt, oracle, renderer, name, w, h, spp, depth, slots):
