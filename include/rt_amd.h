@@ -81,8 +81,10 @@ enum {
     RT_OPT_TAIL_SAMPLES = 9, /* samples per pixel in that tail; -1 (default) = automatic */
     RT_OPT_RESOLVE = 10     /* how the exact hit test walks the candidates the sphere filter left (LDS-staged scenes;
                                results are identical): 0 = automatic (default): pooled over the wave, and for scenes
-                               whose lines cross many spheres (nested shells; decided at scene upload) dense candidate
-                               words lane by lane, four candidates in flight; 1 = always pooled; 2 = always lane by lane */
+                               whose lines cross many spheres (nested shells; decided at scene upload) candidates that
+                               cannot win are struck first (bounding balls per 32 and 8 consecutive spheres, then a
+                               test per sphere) and dense candidate words go lane by lane, four candidates in flight;
+                               1 = always pooled; 2 = always struck and lane by lane */
 };
 
 /* setupMetal (ContentView.swift:328-356): device, queue, pipelines.  `device` is the HIP device ordinal.
