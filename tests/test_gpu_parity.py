@@ -927,6 +927,42 @@ def test_pruned_exact_pass_on_dense_scenes(rt, oracle, renderer, kind):
     assert np.array_equal(bits(imgs[1]), bits(oracle.image(u, arr, w, h)))
 
 
+@pytest.mark.parametrize("case", ["three_spheres", "cornell", "odd_600", "scalar_cache_1500"])
+def test_pruned_exact_pass_on_ordinary_scenes(rt, oracle, renderer, case):
+    """RT_OPT_RESOLVE 2 puts every round of every scene through the bound, the bounding balls and the single-sphere prune
+    (scenes the automatic choice would never send there): a handful of objects, quads, spheres that are not numbers or
+    have radius 0, a negative radius, duplicates, an enclosing sphere; LDS-staged and scalar-cache kinds."""
+    fetch = 1 if case == "scalar_cache_1500" else 0
+    strict(renderer, rt, fetch=fetch)
+    w, h, spp, depth = 96, 54, 4, 30
+    if case in ("three_spheres", "cornell"):
+        objs, n = rt.scene(case)
+        u = rt.config_uniforms(case, w, h, spp, depth, n)
+    else:
+        n0 = 580 if case == "odd_600" else 1480
+        base, _ = rt.scene("random_spheres", n=n0 - 1, extent=6.0)
+        glass = rt.SwiftMaterial.dielectric(1.5)
+        red = rt.SwiftMaterial.lambertian(0.9, 0.1, 0.1)
+        extra = [rt.Object.from_buffer_copy(base[i]) for i in (7, 300, n0 - 1)]
+        for e in extra:
+            e.mat = red
+        extra += [rt.makeSphere((0.5, 0.3, 0.5), 0.3, glass), rt.makeSphere((0.5, 0.3, 0.5), 0.2, red),
+                  rt.makeSphere((0.5, 0.3, 0.5), 0.3, red), rt.makeSphere((1.0, 0.2, 1.0), 0.0, red),
+                  rt.makeSphere((2.0, 0.5, -1.0), -0.5, glass), rt.makeSphere((3.0, 0.5, 1.0), float("nan"), red),
+                  rt.makeSphere((float("nan"), 0.5, 1.0), 0.3, red), rt.makeSphere((0.0, 0.0, 0.0), 300.0, glass),
+                  rt.makeSphere((5000.0, 100.0, -3000.0), 50.0, red)]
+        n = n0 + len(extra)
+        objs = (rt.Object * n)(*([base[i] for i in range(n0)] + extra))
+        u = rt.config_uniforms("random_spheres", w, h, spp, depth, n)
+    renderer.setupTexture(w, h)
+    renderer.set_option(rt.RT_OPT_RESOLVE, 2)
+    try:
+        img = renderer.renderImage(u, objs, n)
+    finally:
+        strict(renderer, rt)
+    assert np.array_equal(bits(img), bits(oracle.image(u, objs, w, h)))
+
+
 @pytest.mark.parametrize("name,w,h,spp,depth,slots", [("cornell", 120, 96, 8, 10, 1 << 20), ("nested_glass", 96, 54, 4, 100, 2048),
                                                        ("three_spheres", 400, 225, 20, 50, 4096)])
 def test_wavefront_kernels_bit_exact(rt, oracle, renderer, name, w, h, spp, depth, slots):
