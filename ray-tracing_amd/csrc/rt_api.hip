@@ -394,8 +394,9 @@ bool dense_scene(const std::vector<float4> &sph, int nsph) {  // the first nsph 
 // one centre C (the component-wise median of the group's centres, rounded to float): an outer ball (C, Rout) that
 // holds every sphere of the group and an inner ball (C, Rin) that every sphere of the group holds.  Spheres that
 // would blow the outer ball up (|c - C| + r above four times the group's median of that number: a ground sphere
-// among small ones) are left out of both balls and listed in a mask of exempt slots, which a prune of the group
-// leaves standing.  Stored squared and with the margins the kernel's argument needs: R2out = Rout^2 (1 + 2^-6)
+// among small ones), or that do not hold C where three quarters of the group do (a small sphere among shells: it
+// would cost the group its inner ball), are left out of both balls and listed in a mask of exempt slots, which a
+// prune of the group leaves standing.  Stored squared and with the margins the kernel's argument needs: R2out = Rout^2 (1 + 2^-6)
 // rounded up, R2in = Rin^2 (1 - 2^-6) rounded down, and no inner ball (R2in = -1) unless Rin > 0 and the largest radius
 // of the group is at most 64 Rin.  A group with a sphere that is not finite, or without spheres, gets R2out = +inf
 // and R2in = -1: never pruned.  Layout: kBoundVec4 float4 per word: (C, R2out), (R2in, exempt mask bits, 0, 0) of the
@@ -427,11 +428,15 @@ void group_bounds(const std::vector<float4> &sph, int i0, int i1, int word0, flo
     std::vector<double> sorted = reach;
     std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
     const double limit = 4.0 * sorted[(size_t)(n / 2)];
+    // when three quarters of the group hold the centre, the others (a small sphere among shells) stay out of the balls too
+    int holding = 0;
+    for (int i = i0; i < i1; ++i) holding += std::fabs((double)sph[(size_t)i].w) > dist[(size_t)(i - i0)] ? 1 : 0;
+    const bool shells = 4 * holding >= 3 * n;
     double rout = 0.0, rin = std::numeric_limits<double>::infinity(), rmax = 0.0;
     uint32_t exempt = 0;
     for (int i = i0; i < i1; ++i) {
         const double r = std::fabs((double)sph[(size_t)i].w);
-        if (reach[(size_t)(i - i0)] > limit) {
+        if (reach[(size_t)(i - i0)] > limit || (shells && !(r > dist[(size_t)(i - i0)]))) {
             exempt |= 0x80000000u >> (i - word0);
             continue;
         }

@@ -18,6 +18,7 @@ constexpr int kRoundWords = 16;   // candidate words per resolve round (512 sphe
 constexpr int kListOffset = kRoundWords * 64;        // after a wave's candidate words: 64 words of candidate list ...
 constexpr int kBestOffset = kListOffset + 64;        // ... and 64 x 64 bits of (distance, slot) minima (resolve_balanced)
 constexpr int kMaskWordsPerWave = kBestOffset + 128; // LDS words per wave
+constexpr int kRestPerLane = 12;   // dense rounds: candidates per lane after the prune up to which every lane resolves its own
 constexpr int kDenseWordBits = 8;  // candidates in a word of 32 spheres from which the word counts as dense (closest_sphere)
 
 // Filter margins (see closest_sphere).  kDirScale inflates the b side of both filters; the c side is inflated
@@ -223,7 +224,7 @@ struct Prof {
 // took part in, and 64-sphere blocks it put through the matrix-core filter (8 matrix instructions each).
 struct Work {
     uint32_t trips = 0, blocks = 0;
-    bool dense = false;  // the wave's last closest-hit search had dense candidate words (closest_sphere)
+    uint32_t unpaid = 0; // (DENSE kernels) rounds in a row in which resolve_dense_words did not pay, up to 4 (closest_sphere)
     int last_slot = 0;   // per lane (the only member that is): the sphere slot this lane's path hit last (dense rounds
                          // resolve the candidates next to it first)
 };
@@ -749,9 +750,12 @@ RT_DEV uint32_t cull_words(const float4 *word_bounds, uint32_t *wave_masks, uint
 }
 // The same a granule of 8 spheres at a time, every lane going through its own remaining words (the balls come
 // through vector loads: the words differ from lane to lane).
-RT_DEV uint32_t cull_granules(const float4 *word_bounds, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, const PruneRay &y) {
+RT_DEV uint32_t cull_granules(const float4 *word_bounds, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, const PruneRay &y,
+                              int &before, int &after) {
     const float4 *balls = word_bounds + kBoundVec4 * (slot0 >> 5);
     uint32_t todo = nz;
+    before = 0;  // candidates in the words the lane came with, and how many of them the balls left
+    after = 0;
     while (__builtin_amdgcn_ballot_w64(todo != 0u)) {
         const bool live = todo != 0u;
         const int w = live ? __builtin_ctz(todo) : 0;  // a lane that is through looks at the round's first word again
@@ -766,8 +770,10 @@ RT_DEV uint32_t cull_granules(const float4 *word_bounds, uint32_t *wave_masks, u
             const bool gone = no_root_up_to_t(b[2 * g].x, b[2 * g].y, b[2 * g].z, b[2 * g + 1].x, b[2 * g].w, 0x1p-8f, y);
             kill |= gone ? (0xFF000000u >> (8 * g)) & ~__float_as_uint(b[2 * g + 1].y) : 0u;
         }
-        if (live && kill) {
+        if (live) {
             const uint32_t m = wave_masks[w * 64 + lane];
+            before += __builtin_popcount(m);
+            after += __builtin_popcount(m & ~kill);
             if (m & kill) {
                 wave_masks[w * 64 + lane] = m & ~kill;
                 if ((m & ~kill) == 0u) nz &= ~(1u << w);
@@ -777,11 +783,13 @@ RT_DEV uint32_t cull_granules(const float4 *word_bounds, uint32_t *wave_masks, u
     return nz;
 }
 // Every lane walks its own candidate words (four candidates per turn, as resolve_word_per_lane takes them), strikes
-// what cannot win and writes the words back; returns the lane's non-empty words.
+// what cannot win and writes the words back; returns the lane's non-empty words and, in left, how many candidates
+// they hold.
 template <typename F>
-RT_DEV uint32_t prune_candidates(const F &f, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, const PruneRay &y) {
+RT_DEV uint32_t prune_candidates(const F &f, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, const PruneRay &y, int &left) {
     uint32_t todo = nz, m = 0, word = 0, gone = 0;
     int w = 0;
+    left = 0;  // candidates the lane has left
     for (;;) {
         if (m == 0) {
             if (gone) {
@@ -790,6 +798,8 @@ RT_DEV uint32_t prune_candidates(const F &f, uint32_t *wave_masks, uint32_t nz, 
                 if (word == 0u) nz &= ~(1u << w);
                 gone = 0;
             }
+            left += __builtin_popcount(word);
+            word = 0;
             if (todo) {
                 w = __builtin_ctz(todo);
                 todo &= todo - 1;
@@ -814,16 +824,67 @@ RT_DEV uint32_t prune_candidates(const F &f, uint32_t *wave_masks, uint32_t nz, 
     return nz;
 }
 
+// The exact pass over what a lane has left, every lane taking its next four candidates wherever its words hold them
+// (resolve_word_per_lane goes word by word for the whole wave, which costs a turn per word when a few candidates are
+// spread over several).  Empties the words it reads from nz.
+template <typename F, bool PROF>
+RT_DEV uint32_t resolve_rest_per_lane(const F &f, const uint32_t *wave_masks, uint32_t nz, int slot0, int lane, V3 o, V3 d, const RootDiv &dv,
+                                      LaneBest &best, Prof<PROF> &prof) {
+    uint32_t m = 0;
+    int w = 0;
+    for (;;) {
+        int s[4];
+        bool v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (m == 0u && nz != 0u) {
+                w = __builtin_ctz(nz);
+                nz &= nz - 1;
+                m = wave_masks[w * 64 + lane];
+            }
+            v[i] = m != 0u;
+            const int p = v[i] ? __builtin_clz(m) : 0;
+            m = v[i] ? m & ~(0x80000000u >> p) : 0u;
+            s[i] = v[i] ? slot0 + w * 32 + p : slot0;  // a lane that is through reads the round's first sphere and accepts nothing
+        }
+        if (__builtin_amdgcn_ballot_w64(v[0]) == 0) break;
+        if constexpr (PROF) {
+            prof.count(6);
+            prof.count(7, (uint64_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(v[0])) + (uint64_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(v[1])) +
+                              (uint64_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(v[2])) + (uint64_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(v[3])));
+        }
+        f4v c0 = f.load1(s[0]), c1 = f.load1(s[1]), c2 = f.load1(s[2]), c3 = f.load1(s[3]);
+        asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+        const float none = -__builtin_inff();
+        const float n0 = v[0] ? best.n : none, n1 = v[1] ? best.n : none, n2 = v[2] ? best.n : none, n3 = v[3] ? best.n : none;
+        const LaneRoot r0 = lane_root(c0, o, d, dv, n0), r1 = lane_root(c1, o, d, dv, n1);
+        const LaneRoot r2 = lane_root(c2, o, d, dv, n2), r3 = lane_root(c3, o, d, dv, n3);
+        lane_offer(best, r0, (uint32_t)s[0]);
+        lane_offer(best, r1, (uint32_t)s[1]);
+        lane_offer(best, r2, (uint32_t)s[2]);
+        lane_offer(best, r3, (uint32_t)s[3]);
+        if (__builtin_amdgcn_ballot_w64((v[0] & r0.retry) | (v[1] & r1.retry) | (v[2] & r2.retry) | (v[3] & r3.retry))) {
+            if (v[0]) lane_retry(best, r0, (uint32_t)s[0], dv, n0);
+            if (v[1]) lane_retry(best, r1, (uint32_t)s[1], dv, n1);
+            if (v[2]) lane_retry(best, r2, (uint32_t)s[2], dv, n2);
+            if (v[3]) lane_retry(best, r3, (uint32_t)s[3], dv, n3);
+        }
+    }
+    return 0u;
+}
+
 // Dense rounds (most lanes hold many candidates: rays among nested shells collect every shell their line crosses).
 // (1) Probe: the four candidates next to the sphere the lane's path hit last (two at or before it in slot order, two
 // after it) are resolved exactly; among nested shells in radius order the next hit is one of them, elsewhere it is
 // merely a bound.  (2) With that bound whole words are struck (cull_words), then single candidates of the remaining
-// words (prune_candidates), and the survivors written back.  (3) Words
-// that are still dense in most lanes are resolved per lane and struck from nz, the others are left to the pooled
-// form.  all = true: every word per lane.
+// words (prune_candidates), and the survivors written back.  (3) When no lane has more than kRestPerLane candidates
+// left, every lane resolves its own (resolve_rest_per_lane).  Otherwise words that are still dense in most lanes are
+// resolved per lane and struck from nz, the others are left to the pooled form; all = true: every word per lane.
+// paid: the balls struck two thirds of the candidates of the lanes that came with three or more words (the caller's
+// cue to come back).
 template <typename F, bool PROF>
 RT_DEV uint32_t resolve_dense_words(const F &f, const float4 *word_bounds, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, V3 o,
-                                    V3 d, const RootDiv &dv, bool all, int hint, Prof<PROF> &prof) {
+                                    V3 d, const RootDiv &dv, bool all, int hint, bool &paid, Prof<PROF> &prof) {
     // the lane's closest (distance, slot) so far lives in LDS beside the pooled form's minima (closest_sphere); it is
     // held in registers only here, so that the sphere filter does not carry it
     unsigned long long *best_lds = (unsigned long long *)(wave_masks + kBestOffset);
@@ -895,22 +956,37 @@ RT_DEV uint32_t resolve_dense_words(const F &f, const float4 *word_bounds, uint3
     y.t = y.has_t ? best.t : 0.0f;
     y.t2 = 2.0f * y.t;
     y.t2a = y.t * y.t * y.a;
-    nz = cull_words(word_bounds, wave_masks, nz, slot0, lane, y);  // (2)
-    nz = cull_granules(word_bounds, wave_masks, nz, slot0, lane, y);
-    nz = prune_candidates(f, wave_masks, nz, slot0, lane, y);
-    // words that are non-empty in some lane (wave-uniform)
-    uint32_t any = nz;
+    // (2) ... and did the balls strike two thirds of the candidates of the lanes that came with three or more words?
+    // (a word struck as a whole is taken for kDenseWordBits candidates; before in the upper half, after in the lower)
+    const int words0 = __builtin_popcount(nz);
+    nz = cull_words(word_bounds, wave_masks, nz, slot0, lane, y);
+    int before, after;
+    const int struck = words0 - __builtin_popcount(nz);
+    nz = cull_granules(word_bounds, wave_masks, nz, slot0, lane, y, before, after);
+    int tally = words0 >= 3 ? ((before + kDenseWordBits * struck) << 16) | after : 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) any |= (uint32_t)__shfl_xor((int)any, off, 64);
-    any = (uint32_t)__builtin_amdgcn_readfirstlane((int)any);
-    while (any) {  // (3)
-        const int w = __builtin_ctz(any);
-        any &= any - 1;
-        const uint32_t m = (nz >> w) & 1u ? wave_masks[w * 64 + lane] : 0u;
-        const uint64_t dense = __builtin_amdgcn_ballot_w64(__builtin_popcount(m) >= kDenseWordBits);
-        if (all || __builtin_popcountll(dense) >= 32) {
-            resolve_word_per_lane(f, m, slot0 + w * 32, o, d, dv, best, prof);
-            nz &= ~(1u << w);
+    for (int off = 32; off > 0; off >>= 1) tally += __shfl_xor(tally, off, 64);
+    paid = 3 * (tally & 0xFFFF) <= (tally >> 16);
+    int left;
+    nz = prune_candidates(f, wave_masks, nz, slot0, lane, y, left);
+    if (__builtin_amdgcn_ballot_w64(left > kRestPerLane) == 0) {
+        // (3a) few left in every lane: each lane resolves its own, across its words
+        nz = resolve_rest_per_lane(f, wave_masks, nz, slot0, lane, o, d, dv, best, prof);
+    } else {
+        // (3b) words that are non-empty in some lane (wave-uniform)
+        uint32_t any = nz;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) any |= (uint32_t)__shfl_xor((int)any, off, 64);
+        any = (uint32_t)__builtin_amdgcn_readfirstlane((int)any);
+        while (any) {
+            const int w = __builtin_ctz(any);
+            any &= any - 1;
+            const uint32_t m = (nz >> w) & 1u ? wave_masks[w * 64 + lane] : 0u;
+            const uint64_t dense = __builtin_amdgcn_ballot_w64(__builtin_popcount(m) >= kDenseWordBits);
+            if (all || __builtin_popcountll(dense) >= 32) {
+                resolve_word_per_lane(f, m, slot0 + w * 32, o, d, dv, best, prof);
+                nz &= ~(1u << w);
+            }
         }
     }
     best_lds[lane] = ((unsigned long long)__float_as_uint(best.t) << 32) | best.slot;
@@ -984,24 +1060,24 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
         if (!a_ok || !active) nz = 0;
         prof.lap(1);
         // Which form of pass B: pooled over the wave (the usual case: a couple of candidates per ray, a few lanes with
-        // more), except for words of 32 spheres in which most lanes hold many candidates (nested shells): those go lane
-        // by lane.  That code is only part of the kernels launched for scenes in which rays cross many spheres (DENSE;
-        // the host decides at scene upload), so that the usual kernels do not pay for it in registers.  Looking for
-        // dense words costs a pass over the words, so it is only done when a quarter of the lanes have three or more
-        // non-empty words and the first of them is dense; and a wave that found no such round asks again only on every
-        // eighth of its searches.  (A wave with a ray whose a = d.d is out of the range of the shared-reciprocal
-        // division stays pooled.)
+        // more), or, in rounds with long candidate lists (nested shells), the form that strikes what cannot win and
+        // resolves the rest lane by lane (resolve_dense_words).  That code is only part of the kernels launched for
+        // scenes in which rays cross many spheres (DENSE; the host decides at scene upload), so that the usual kernels
+        // do not pay for it in registers.  A round qualifies when some lane has four or more non-empty words (the
+        // pool's loop over layers is as long as the longest list, however few lanes have one).  Whether the form pays
+        // is learnt from its own result: it reports whether the bounding balls struck two thirds of the candidates,
+        // and a wave that did not see that in four qualifying rounds in a row goes back to the pool and tries again
+        // only on every sixteenth of its searches (sending a round of long lists to the pool costs several times what
+        // a round that does not pay costs here, hence the patience).  (A wave with a ray whose a = d.d is out of the
+        // range of the shared-reciprocal division stays pooled.)
         if constexpr (DENSE) {
             if (P.resolve_mode != 1 && !dv.slow) {
-                bool look = P.resolve_mode == 2;
-                if (!look && (work.dense || (work.trips & 7u) == 0u)) {
-                    if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(__builtin_popcount(nz) >= 3)) >= 16) {
-                        const uint32_t first = nz ? wave_masks[__builtin_ctz(nz) * 64 + lane] : 0u;
-                        look = __builtin_popcountll(__builtin_amdgcn_ballot_w64(__builtin_popcount(first) >= kDenseWordBits)) >= 16;
-                    }
-                    work.dense = look;
+                const bool qualifies = __builtin_amdgcn_ballot_w64(__builtin_popcount(nz) >= 4) != 0;
+                if (P.resolve_mode == 2 || (qualifies && (work.unpaid < 4u || (work.trips & 15u) == 0u))) {
+                    bool paid;
+                    nz = resolve_dense_words(f, P.word_bounds, wave_masks, nz, 4 * g0, lane, o, d, dv, P.resolve_mode == 2, work.last_slot, paid, prof);
+                    if (qualifies) work.unpaid = paid ? 0u : min(work.unpaid + 1u, 4u);
                 }
-                if (look) nz = resolve_dense_words(f, P.word_bounds, wave_masks, nz, 4 * g0, lane, o, d, dv, P.resolve_mode == 2, work.last_slot, prof);
             }
         }
         resolve_balanced(f, wave_masks, nz, 4 * g0, lane, o, d, dv, prof);
