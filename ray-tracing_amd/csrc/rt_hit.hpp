@@ -696,8 +696,10 @@ RT_DEV void resolve_word_per_lane(const F &f, uint32_t m, int base, V3 o, V3 d, 
 // then |g(t)| > M puts the exit 2^-11 r / |d| beyond t (the reference's exit root is within 2^-21 r / |d|) and a
 // grazing entry 2^-8.8 sqrt(X) / |d| beyond t (the reference's first root of a near-zero discriminant is within
 // 2^-10.2 sqrt(X) / |d|; away from grazing both bounds grow apart); in the second case the reference's numerators
-// are not positive whatever the rounding, given the signs of its b and c.  A word: m = 2^-8 and the balls are
-// widened by 2^-6, which keeps every root of every sphere of the word 2^-9 sqrt(X) / |d| outside [0, t].  The signs of
+// are not positive whatever the rounding, given the signs of its b and c.  A word: the balls are widened by 2^-6 and
+// m = 2^-8 in the comparisons against the outer ball, which keeps every root of every sphere of the word
+// 2^-9 sqrt(X) / |d| outside [0, t]; against the inner ball m = 2^-15 is enough, because a ray that starts and ends
+// 2^-7 of the inner radius inside every sphere grazes none of them (every exit is 2^-13 r / |d| beyond t).  The signs of
 // u.d and u.d + t a are taken only when clear of their rounding (2^-19 and 2^-18 of |u||d|, sqrt(X)|d|).  NaN or
 // infinite operands pass no comparison.  has_t = false (no accepted root yet): only the second case applies.
 struct PruneRay {
@@ -705,39 +707,58 @@ struct PruneRay {
     float k1, a, a38, a36, t, t2, t2a;  // 2^-21 |o|^2, d.d, 2^-38 a, 2^-36 a, best root t, 2 t, t^2 a
     bool has_t;
 };
-RT_DEV bool no_root_up_to_t(float cx, float cy, float cz, float r2in, float r2out, float m, const PruneRay &y) {
+// The ray against one centre: everything in the three tests but the radii (groups of one scene often share a centre).
+struct PruneAbout {
+    float so, sp, X;      // |o - c|^2, |P - c|^2, the margins' scale
+    bool behind, ahead;   // u.d > 0, u.d + t a < 0, both clear of their rounding
+};
+RT_DEV PruneAbout prune_about(float cx, float cy, float cz, const PruneRay &y) {
     const float ux = y.o.x - cx, uy = y.o.y - cy, uz = y.o.z - cz;
-    const float so = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+    PruneAbout q;
+    q.so = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
     const float bf = __builtin_fmaf(uz, y.d.z, __builtin_fmaf(uy, y.d.y, ux * y.d.x));
-    const float pd = __builtin_fmaf(y.t, y.a, bf);      // (P - c).d
-    const float sp = __builtin_fmaf(y.t, pd + bf, so);  // |P - c|^2
-    const float X = __builtin_fmaf(y.t2, __builtin_fabsf(bf), so + y.t2a);
-    const float M = __builtin_fmaf(m, X, y.k1);
-    const bool neg = (so + M < r2in) & (sp + M < r2in);
-    const bool pos0 = so - M > r2out, post = sp - M > r2out;
-    const bool behind = (bf > 0.0f) & (bf * bf > so * y.a38);
-    const bool ahead = (pd < 0.0f) & (pd * pd > X * y.a36);
-    return (pos0 & behind) | (y.has_t & (neg | (pos0 & post & ahead)));
+    const float pd = __builtin_fmaf(y.t, y.a, bf);  // (P - c).d
+    q.sp = __builtin_fmaf(y.t, pd + bf, q.so);
+    q.X = __builtin_fmaf(y.t2, __builtin_fabsf(bf), q.so + y.t2a);
+    q.behind = (bf > 0.0f) & (bf * bf > q.so * y.a38);
+    q.ahead = (pd < 0.0f) & (pd * pd > q.X * y.a36);
+    return q;
+}
+// m_in, m_out: the margins' m of the inside and of the outside comparisons.
+RT_DEV bool no_root_up_to_t(const PruneAbout &q, float r2in, float r2out, float m_in, float m_out, const PruneRay &y) {
+    const float Mi = __builtin_fmaf(m_in, q.X, y.k1), Mo = __builtin_fmaf(m_out, q.X, y.k1);
+    const bool neg = (q.so + Mi < r2in) & (q.sp + Mi < r2in);
+    const bool pos0 = q.so - Mo > r2out, post = q.sp - Mo > r2out;
+    return (pos0 & q.behind) | (y.has_t & (neg | (pos0 & post & q.ahead)));
 }
 RT_DEV bool cannot_win(f4v rec, const PruneRay &y) {
     const float r2 = rec.w * rec.w;
-    return no_root_up_to_t(rec.x, rec.y, rec.z, __builtin_fmaf(-0x1p-10f, r2, r2), __builtin_fmaf(0x1p-10f, r2, r2), 0x1p-15f, y);
+    return no_root_up_to_t(prune_about(rec.x, rec.y, rec.z, y), __builtin_fmaf(-0x1p-10f, r2, r2), __builtin_fmaf(0x1p-10f, r2, r2), 0x1p-15f,
+                           0x1p-15f, y);
 }
+constexpr float kBallMarginIn = 0x1p-15f, kBallMarginOut = 0x1p-8f;
 // Strikes the words whose 32 spheres cannot win as a whole (wave-uniform loop over the words that are non-empty in
-// some lane; the balls come through scalar loads).  Slots the word's balls leave out (exempt) stay.  Returns the
-// lane's remaining non-empty words.
+// some lane; the balls come through scalar loads, and a word about the same centre as the one before reuses the
+// ray's numbers about it).  Slots the word's balls leave out (exempt) stay.  Returns the lane's remaining non-empty
+// words.
 RT_DEV uint32_t cull_words(const float4 *word_bounds, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, const PruneRay &y) {
     const const_f4_ptr balls = (const_f4_ptr)(uintptr_t)word_bounds + kBoundVec4 * (slot0 >> 5);
     uint32_t any = nz;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) any |= (uint32_t)__shfl_xor((int)any, off, 64);
     any = (uint32_t)__builtin_amdgcn_readfirstlane((int)any);
+    float pcx = __builtin_nanf(""), pcy = pcx, pcz = pcx;  // the centre q is about (none yet)
+    PruneAbout q = {};
     while (any) {
         const int w = __builtin_ctz(any);
         any &= any - 1;
         const f4v outer = balls[kBoundVec4 * w], inner = balls[kBoundVec4 * w + 1];
         const uint32_t exempt = __float_as_uint(inner.y);  // wave-uniform
-        if (no_root_up_to_t(outer.x, outer.y, outer.z, inner.x, outer.w, 0x1p-8f, y) && ((nz >> w) & 1u)) {
+        if (!(outer.x == pcx && outer.y == pcy && outer.z == pcz)) {
+            q = prune_about(outer.x, outer.y, outer.z, y);
+            pcx = outer.x; pcy = outer.y; pcz = outer.z;
+        }
+        if (no_root_up_to_t(q, inner.x, outer.w, kBallMarginIn, kBallMarginOut, y) && ((nz >> w) & 1u)) {
             uint32_t m = 0;
             if (exempt) {
                 m = wave_masks[w * 64 + lane] & exempt;
@@ -749,7 +770,8 @@ RT_DEV uint32_t cull_words(const float4 *word_bounds, uint32_t *wave_masks, uint
     return nz;
 }
 // The same a granule of 8 spheres at a time, every lane going through its own remaining words (the balls come
-// through vector loads: the words differ from lane to lane).
+// through vector loads: the words differ from lane to lane).  When the four granules of every lane's word share
+// their centre, the ray's numbers about it are worked out once.
 RT_DEV uint32_t cull_granules(const float4 *word_bounds, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, const PruneRay &y,
                               int &before, int &after) {
     const float4 *balls = word_bounds + kBoundVec4 * (slot0 >> 5);
@@ -760,15 +782,28 @@ RT_DEV uint32_t cull_granules(const float4 *word_bounds, uint32_t *wave_masks, u
         const bool live = todo != 0u;
         const int w = live ? __builtin_ctz(todo) : 0;  // a lane that is through looks at the round's first word again
         todo &= todo - 1;
-        const float4 *q = balls + kBoundVec4 * w + 2;
+        const float4 *g4 = balls + kBoundVec4 * w + 2;
         float4 b[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) b[k] = q[k];
-        uint32_t kill = 0;
+        for (int k = 0; k < 8; ++k) b[k] = g4[k];
+        bool same = true;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const bool gone = no_root_up_to_t(b[2 * g].x, b[2 * g].y, b[2 * g].z, b[2 * g + 1].x, b[2 * g].w, 0x1p-8f, y);
-            kill |= gone ? (0xFF000000u >> (8 * g)) & ~__float_as_uint(b[2 * g + 1].y) : 0u;
+        for (int g = 1; g < 4; ++g) same = same & (b[2 * g].x == b[0].x) & (b[2 * g].y == b[0].y) & (b[2 * g].z == b[0].z);
+        uint32_t kill = 0;
+        if (__builtin_amdgcn_ballot_w64(!same) == 0) {
+            const PruneAbout q = prune_about(b[0].x, b[0].y, b[0].z, y);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const bool gone = no_root_up_to_t(q, b[2 * g + 1].x, b[2 * g].w, kBallMarginIn, kBallMarginOut, y);
+                kill |= gone ? (0xFF000000u >> (8 * g)) & ~__float_as_uint(b[2 * g + 1].y) : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const PruneAbout q = prune_about(b[2 * g].x, b[2 * g].y, b[2 * g].z, y);
+                const bool gone = no_root_up_to_t(q, b[2 * g + 1].x, b[2 * g].w, kBallMarginIn, kBallMarginOut, y);
+                kill |= gone ? (0xFF000000u >> (8 * g)) & ~__float_as_uint(b[2 * g + 1].y) : 0u;
+            }
         }
         if (live) {
             const uint32_t m = wave_masks[w * 64 + lane];
