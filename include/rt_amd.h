@@ -220,6 +220,16 @@ RT_API int rt_selftest_matrix_filter(rt_ctx *ctx, uint32_t seed, int blocks, int
  * relative slack and the distance-dependent one; -16 is what the library renders with.  Same outputs. */
 RT_API int rt_selftest_tiled_filter(rt_ctx *ctx, uint32_t seed, int blocks, int rounds, int slack_log2, uint64_t out[6]);
 
+/* No counterpart in the reference.  Host-only (no device, no context): the bounding balls the library builds at scene
+ * upload for the kernels that prune candidates a group at a time, for `count` spheres given as (x, y, z, radius) in slot
+ * order.  out receives RT_BOUND_FLOATS floats per word of 32 slots ((count + 31) / 32 words): (Cx, Cy, Cz, R2out),
+ * (R2in, exempt mask bits, 0, 0) for the word, then the same pair for each of its four granules of 8 slots.  Every
+ * sphere of a group that is not exempt lies inside the ball (C, sqrt(R2out / (1 + 2^-6))) and contains the ball
+ * (C, sqrt(R2in / (1 - 2^-6))); R2in < 0: no inner ball; mask bit of slot p of the word: 0x80000000 >> p.
+ * Returns the number of words, or RT_ERR_INVALID. */
+#define RT_BOUND_FLOATS 40
+RT_API int rt_group_bounds(const float *spheres_xyzr, int count, float *out);
+
 #ifdef __cplusplus
 }
 #endif

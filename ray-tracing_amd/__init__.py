@@ -108,7 +108,7 @@ AMD_SYMBOLS = [
     "rt_write_target", "rt_read_target", "rt_render_tile", "rt_present_bgra8", "rt_set_scene", "rt_render",
     "rt_render_noalloc",
     "rt_accum_clear", "rt_accum_ptr", "rt_resolve", "rt_synchronize", "rt_first_hit", "rt_last_stats", "rt_trace_times",
-    "rt_selftest_filter", "rt_selftest_matrix_filter", "rt_selftest_tiled_filter",
+    "rt_selftest_filter", "rt_selftest_matrix_filter", "rt_selftest_tiled_filter", "rt_group_bounds",
 ]
 HOST_SYMBOLS = [
     "rt_material_default", "rt_material_lambertian", "rt_material_metal", "rt_material_dielectric", "rt_material_light",
@@ -154,6 +154,7 @@ def amd_lib():
         lib.rt_selftest_filter.argtypes = [vp, C.c_uint32, ip, ip, vp]
         lib.rt_selftest_matrix_filter.argtypes = [vp, C.c_uint32, ip, ip, ip, vp]
         lib.rt_selftest_tiled_filter.argtypes = [vp, C.c_uint32, ip, ip, ip, vp]
+        lib.rt_group_bounds.argtypes = [vp, ip, vp]
         _amd = lib
     return _amd
 
@@ -276,6 +277,20 @@ def config_uniforms(name, width, height, spp, depth, objCount):
         raise ValueError(name)
     u.objCount = objCount
     return u
+
+
+def group_bounds(spheres):
+    """Bounding balls per word of 32 and granule of 8 sphere slots as the library builds them at scene upload (host
+    only).  spheres: (n, 4) float32 (x, y, z, radius).  Returns (words, 5, 2, 4) float32: [word, 0] the word's pair
+    (C, R2out), (R2in, exempt bits, 0, 0); [word, 1 + g] the pair of granule g."""
+    import numpy as np
+    sph = np.ascontiguousarray(spheres, dtype=np.float32).reshape(-1, 4)
+    words = (len(sph) + 31) // 32
+    out = np.zeros((max(words, 1), 5, 2, 4), np.float32)
+    n = amd_lib().rt_group_bounds(sph.ctypes.data, len(sph), out.ctypes.data)
+    if n < 0:
+        raise RtError(n, "rt_group_bounds")
+    return out[:n]
 
 
 def generate_tiles(width, height, tileSize=64):

@@ -1258,6 +1258,17 @@ RT_API int rt_selftest_tiled_filter(rt_ctx *ctx, uint32_t seed, int blocks, int 
     return selftest_matrix(ctx, seed, blocks, rounds, slack_log2, 1, out);
 }
 
+RT_API int rt_group_bounds(const float *spheres_xyzr, int count, float *out) {
+    static_assert(RT_BOUND_FLOATS == 4 * kBoundVec4, "rt_amd.h and rt_kernels.h disagree about the bounds record");
+    if (count < 0 || (count > 0 && !spheres_xyzr) || !out) return RT_ERR_INVALID;
+    std::vector<float4> sph((size_t)count);
+    for (int i = 0; i < count; ++i)
+        sph[(size_t)i] = make_float4(spheres_xyzr[4 * i], spheres_xyzr[4 * i + 1], spheres_xyzr[4 * i + 2], spheres_xyzr[4 * i + 3]);
+    const std::vector<float4> b = word_bounds(sph, count);
+    if (!b.empty()) std::memcpy(out, b.data(), b.size() * sizeof(float4));
+    return (int)(b.size() / (size_t)kBoundVec4);
+}
+
 RT_API int rt_trace_times(rt_ctx *ctx, float *ms, int cap, int *count) {
     if (!ctx || !ms || !count || cap < 0) return RT_ERR_INVALID;
     Bind bind(ctx);

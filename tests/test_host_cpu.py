@@ -165,6 +165,61 @@ def test_ray_range_partitions_the_sample_index_space():
     assert part.tile_rows(0, 2, 225) == (0, 128) and part.tile_rows(1, 2, 225) == (128, 225)
 
 
+def test_group_bounds_hold_what_the_prune_assumes(rt):
+    """The kernels for scenes whose rays cross many spheres strike a whole group of candidates with two balls about one
+    centre: every sphere of the group that is not listed as exempt must lie inside the outer ball and contain the
+    inner one, with the stated margins, and the largest radius may be at most 64 inner radii.  Checked in binary64
+    on shells (concentric, drifting), clutter, a ground sphere and a small sphere among shells (both must come out
+    exempt), spheres that are not numbers (their groups must never be struck) and a ragged last word."""
+    rng = np.random.default_rng(5)
+    shells = np.array([[0.0, 0.0, -1.0, 0.5 * (1.0 - k / 400.0)] for k in range(400)], np.float32)
+    cases = {
+        "nested": np.vstack([[[0.0, -100.5, -1.0, 100.0]], shells]),
+        "drifting": np.array([[0.002 * k, 0.0, -1.0, 0.5 - 0.002 * k] for k in range(200)], np.float32),
+        "clutter": np.hstack([rng.random((301, 3)) * 1.5, rng.uniform(0.15, 0.5, (301, 1))]),
+        "strays": np.vstack([shells[:40], [[0.3, 0.2, -0.7, 0.05]], shells[40:77]]),
+        "far": shells[:90] * np.array([100, 100, 100, 100]) + np.array([1000.0, 500.0, -2000.0, 0.0]),
+        "negative_radius": np.vstack([shells[:20], [[0.0, 0.0, -1.0, -0.3]], shells[20:31]]),
+    }
+    nan = np.vstack([shells[:64]])
+    nan[5, 3] = np.nan
+    nan[40, 0] = np.inf
+    cases["not_numbers"] = nan
+    for name, sph in cases.items():
+        sph = sph.astype(np.float32)
+        b = rt.group_bounds(sph)
+        assert len(b) == (len(sph) + 31) // 32, name
+        for w in range(len(b)):
+            groups = [(32 * w, min(len(sph), 32 * w + 32), b[w, 0])]
+            groups += [(32 * w + 8 * g, min(len(sph), 32 * w + 8 * g + 8), b[w, 1 + g]) for g in range(4)]
+            for i0, i1, pair in groups:
+                c, r2out, r2in = pair[0, :3].astype(np.float64), float(pair[0, 3]), float(pair[1, 0])
+                exempt = int(pair[1, 1:2].view(np.uint32)[0])
+                members = sph[i0:i1].astype(np.float64)
+                if i1 <= i0 or not np.isfinite(members).all():
+                    assert r2out == np.inf and r2in < 0, (name, w)   # never struck
+                    continue
+                rout = np.sqrt(r2out / (1 + 2.0 ** -6))
+                rin = np.sqrt(r2in / (1 - 2.0 ** -6)) if r2in > 0 else None
+                kept = 0
+                for i, (x, y, z, r) in enumerate(members):
+                    if exempt & (0x80000000 >> (i0 + i - 32 * w)):
+                        continue
+                    kept += 1
+                    dist, r = np.linalg.norm(np.array([x, y, z]) - c), abs(r)
+                    assert dist + r <= rout * (1 + 1e-6), (name, w, i)
+                    if rin is not None:
+                        assert r - dist >= rin * (1 - 1e-6) and r <= 64 * rin * (1 + 1e-6), (name, w, i)
+                assert exempt & ~(((1 << (i1 - i0)) - 1) << (32 - (i1 - 32 * w))) == 0, (name, w)   # only members are listed
+                assert kept > 0 or r2out == 0.0, (name, w)
+    # the ground sphere among shells and the small sphere among shells are exempt, and the shells keep both balls
+    b = rt.group_bounds(cases["nested"].astype(np.float32))
+    assert int(b[0, 0, 1, 1:2].view(np.uint32)[0]) == 0x80000000 and b[0, 0, 1, 0] > 0
+    b = rt.group_bounds(cases["strays"].astype(np.float32))
+    assert int(b[1, 0, 1, 1:2].view(np.uint32)[0]) == 0x80000000 >> 8 and b[1, 0, 1, 0] > 0
+    assert rt.amd_lib().rt_group_bounds(None, -1, None) < 0
+
+
 def test_matrix_results_are_read_at_a_safe_distance():
     """MI355X does not interlock a vector read of a matrix instruction's result (tools/mfma_hazard_probe.hip: result
     register r is written 5 + r/2 wait states after issue, and the ROCm 7.2 compiler spaces reads by 11 where the last
