@@ -220,6 +220,16 @@ RT_API int rt_selftest_matrix_filter(rt_ctx *ctx, uint32_t seed, int blocks, int
  * relative slack and the distance-dependent one; -16 is what the library renders with.  Same outputs. */
 RT_API int rt_selftest_tiled_filter(rt_ctx *ctx, uint32_t seed, int blocks, int rounds, int slack_log2, uint64_t out[6]);
 
+/* No counterpart in the reference.  Self-test of the prune that precedes the exact hit test in scenes whose rays cross
+ * many spheres (RT_OPT_RESOLVE), on the scene set with rt_set_scene: blocks x 256 threads build rays_per_thread rays
+ * each the way paths produce them, with the hard cases made frequent (origins on or a few ulps off a surface,
+ * directions tangent to it or at another sphere's silhouette, bounds equal to another sphere's root or a few ulps
+ * off it), and check every sphere of the scene against every level of the prune.  out[0] (ray, sphere) pairs,
+ * out[1] pairs whose sphere has an accepted root, out[2] pairs the single-sphere test strikes, out[3] pairs the
+ * bounding balls of a word or granule strike, out[4] / out[5] pairs struck by the one / the other although the
+ * root the reference computes is not above the ray's bound: both must be 0. */
+RT_API int rt_selftest_prune(rt_ctx *ctx, uint32_t seed, int blocks, int rays_per_thread, uint64_t out[6]);
+
 /* No counterpart in the reference.  Host-only (no device, no context): the bounding balls the library builds at scene
  * upload for the kernels that prune candidates a group at a time, for `count` spheres given as (x, y, z, radius) in slot
  * order.  out receives RT_BOUND_FLOATS floats per word of 32 slots ((count + 31) / 32 words): (Cx, Cy, Cz, R2out),

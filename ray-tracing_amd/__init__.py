@@ -108,7 +108,7 @@ AMD_SYMBOLS = [
     "rt_write_target", "rt_read_target", "rt_render_tile", "rt_present_bgra8", "rt_set_scene", "rt_render",
     "rt_render_noalloc",
     "rt_accum_clear", "rt_accum_ptr", "rt_resolve", "rt_synchronize", "rt_first_hit", "rt_last_stats", "rt_trace_times",
-    "rt_selftest_filter", "rt_selftest_matrix_filter", "rt_selftest_tiled_filter", "rt_group_bounds",
+    "rt_selftest_filter", "rt_selftest_matrix_filter", "rt_selftest_tiled_filter", "rt_selftest_prune", "rt_group_bounds",
 ]
 HOST_SYMBOLS = [
     "rt_material_default", "rt_material_lambertian", "rt_material_metal", "rt_material_dielectric", "rt_material_light",
@@ -154,6 +154,7 @@ def amd_lib():
         lib.rt_selftest_filter.argtypes = [vp, C.c_uint32, ip, ip, vp]
         lib.rt_selftest_matrix_filter.argtypes = [vp, C.c_uint32, ip, ip, ip, vp]
         lib.rt_selftest_tiled_filter.argtypes = [vp, C.c_uint32, ip, ip, ip, vp]
+        lib.rt_selftest_prune.argtypes = [vp, C.c_uint32, ip, ip, vp]
         lib.rt_group_bounds.argtypes = [vp, ip, vp]
         _amd = lib
     return _amd
@@ -492,6 +493,12 @@ class MetalRenderer:
         out = (C.c_uint64 * 6)()
         self._check(self._lib.rt_selftest_matrix_filter(self._ctx, seed, blocks, rounds, slack_log2, out))
         return dict(zip(["pairs", "reference", "matrix", "missed", "out_of_range", "unflagged"], list(out)))
+
+    def selftestPrune(self, seed=1, blocks=256, rays_per_thread=4):
+        """On the scene set with setScene."""
+        out = (C.c_uint64 * 6)()
+        self._check(self._lib.rt_selftest_prune(self._ctx, seed, blocks, rays_per_thread, out))
+        return dict(zip(["pairs", "reference", "single", "balls", "single_wrong", "balls_wrong"], list(out)))
 
     def selftestTiledFilter(self, seed=1, blocks=1024, rounds=64, slack_log2=-16):
         out = (C.c_uint64 * 6)()

@@ -1235,6 +1235,22 @@ RT_API int rt_selftest_filter(rt_ctx *ctx, uint32_t seed, int blocks, int pairs_
     return RT_OK;
 }
 
+RT_API int rt_selftest_prune(rt_ctx *ctx, uint32_t seed, int blocks, int rays_per_thread, uint64_t out[6]) {
+    if (!ctx || !out || blocks <= 0 || rays_per_thread <= 0) return RT_ERR_INVALID;
+    if (!ctx->scene_resident || ctx->nsph <= 0) return fail(ctx, RT_ERR_NO_SCENE, "rt_selftest_prune: set a scene with spheres first (rt_set_scene)");
+    Bind bind(ctx);
+    RT_TRY(grow(ctx, ctx->staging, 256));
+    unsigned long long *dev = (unsigned long long *)ctx->staging.ptr;
+    hipError_t e = hipMemsetAsync(dev, 0, 256, ctx->stream);
+    if (e == hipSuccess) e = launch_prune_selftest(seed, blocks, rays_per_thread, ctx->sph.ptr, ctx->word_bounds.ptr, ctx->nsph, dev, ctx->stream);
+    unsigned long long host[6] = {0, 0, 0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(host, dev, sizeof host, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_selftest_prune", e);
+    for (int i = 0; i < 6; ++i) out[i] = host[i];
+    return RT_OK;
+}
+
 static int selftest_matrix(rt_ctx *ctx, uint32_t seed, int blocks, int rounds, int slack_log2, int far, uint64_t out[6]) {
     if (!ctx || !out || blocks <= 0 || rounds <= 0 || slack_log2 > -8 || slack_log2 < -30) return RT_ERR_INVALID;
     Bind bind(ctx);

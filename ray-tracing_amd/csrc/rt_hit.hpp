@@ -707,6 +707,20 @@ struct PruneRay {
     float k1, a, a38, a36, t, t2, t2a;  // 2^-21 |o|^2, d.d, 2^-38 a, 2^-36 a, best root t, 2 t, t^2 a
     bool has_t;
 };
+RT_DEV PruneRay make_prune_ray(V3 o, V3 d, float a, bool has_t, float t) {
+    PruneRay y;
+    y.o = o;
+    y.d = d;
+    y.k1 = 0x1p-21f * __builtin_fmaf(o.z, o.z, __builtin_fmaf(o.y, o.y, o.x * o.x));
+    y.a = a;
+    y.a38 = 0x1p-38f * a;
+    y.a36 = 0x1p-36f * a;
+    y.has_t = has_t;
+    y.t = has_t ? t : 0.0f;
+    y.t2 = 2.0f * y.t;
+    y.t2a = y.t * y.t * a;
+    return y;
+}
 // The ray against one centre: everything in the three tests but the radii (groups of one scene often share a centre).
 struct PruneAbout {
     float so, sp, X;      // |o - c|^2, |P - c|^2, the margins' scale
@@ -980,17 +994,7 @@ RT_DEV uint32_t resolve_dense_words(const F &f, const float4 *word_bounds, uint3
             }
         }
     }
-    PruneRay y;
-    y.o = o;
-    y.d = d;
-    y.k1 = 0x1p-21f * __builtin_fmaf(o.z, o.z, __builtin_fmaf(o.y, o.y, o.x * o.x));
-    y.a = dv.a;
-    y.a38 = 0x1p-38f * dv.a;
-    y.a36 = 0x1p-36f * dv.a;
-    y.has_t = best.slot != 0xFFFFFFFFu;
-    y.t = y.has_t ? best.t : 0.0f;
-    y.t2 = 2.0f * y.t;
-    y.t2a = y.t * y.t * y.a;
+    const PruneRay y = make_prune_ray(o, d, dv.a, best.slot != 0xFFFFFFFFu, best.t);
     // (2) ... and did the balls strike two thirds of the candidates of the lanes that came with three or more words?
     // (a word struck as a whole is taken for kDenseWordBits candidates; before in the upper half, after in the lower)
     const int words0 = __builtin_popcount(nz);

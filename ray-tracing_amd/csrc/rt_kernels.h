@@ -108,6 +108,9 @@ hipError_t launch_filter_selftest(uint32_t seed, int blocks, int pairs_per_threa
                                   hipStream_t stream);
 hipError_t launch_matrix_selftest(uint32_t seed, int blocks, int rounds, float slack, int far, unsigned long long *out,
                                   hipStream_t stream);
+// sph: nsph strict records (x, y, z, radius) in slot order; bounds: their bounding balls (TraceParams::word_bounds)
+hipError_t launch_prune_selftest(uint32_t seed, int blocks, int rays_per_thread, const float4 *sph, const float4 *bounds, int nsph,
+                                 unsigned long long *out, hipStream_t stream);
 hipError_t launch_fold(float4 *accum, const float4 *planes, int nplanes, int width, int height, int tileX, int tileY,
                        int tileW, int tileH, hipStream_t stream);
 // The reference's per-pixel epilogue for one pass over a tile (Shaders.metal:142-160) on tile-sized planes that hold one

@@ -927,6 +927,31 @@ def test_pruned_exact_pass_on_dense_scenes(rt, oracle, renderer, kind):
     assert np.array_equal(bits(imgs[1]), bits(oracle.image(u, arr, w, h)))
 
 
+@pytest.mark.parametrize("kind", ["nested_glass", "drifting_shells", "clutter", "far_shells", "shells_and_strays", "cover"])
+def test_prune_strikes_nothing_the_reference_would_take(rt, renderer, kind):
+    """rt_selftest_prune on the scene's own spheres and bounding balls: rays from on or next to surfaces, tangent or
+    aimed at silhouettes, with bounds equal to other spheres' roots or a few ulps off them, every sphere against the
+    single-sphere test and the balls of its word and granule.  Nothing may be struck whose reference root is not above
+    the bound."""
+    if kind in ("nested_glass", "cover"):
+        arr, n = rt.scene(kind)
+    else:
+        objs, _, _ = _dense_scene(rt, kind)
+        n = len(objs)
+        arr = rt.object_array(objs)
+    renderer.setScene(arr, n)
+    tot = {"pairs": 0, "single": 0, "balls": 0, "reference": 0}
+    for seed in (1, 2, 3):
+        r = renderer.selftestPrune(seed=seed, blocks=512, rays_per_thread=4)
+        assert r["single_wrong"] == 0 and r["balls_wrong"] == 0, r
+        for k in tot:
+            tot[k] += r[k]
+    assert tot["pairs"] > 1e8 and tot["reference"] > 0.002 * tot["pairs"]
+    assert tot["single"] > 0.2 * tot["pairs"]                      # the test is not vacuous ...
+    if kind not in ("clutter", "cover"):
+        assert tot["balls"] > 0.2 * tot["pairs"]                   # ... and among shells the balls do most of the work
+
+
 @pytest.mark.parametrize("case", ["three_spheres", "cornell", "odd_600", "scalar_cache_1500"])
 def test_pruned_exact_pass_on_ordinary_scenes(rt, oracle, renderer, case):
     """RT_OPT_RESOLVE 2 puts every round of every scene through the bound, the bounding balls and the single-sphere prune
