@@ -952,6 +952,37 @@ def test_prune_strikes_nothing_the_reference_would_take(rt, renderer, kind):
         assert tot["balls"] > 0.2 * tot["pairs"]                   # ... and among shells the balls do most of the work
 
 
+@pytest.mark.parametrize("shells,path", [(1000, 3), (1500, None)])
+def test_pruned_exact_pass_over_several_rounds(rt, oracle, renderer, shells, path):
+    """1000 and 1500 nested shells: the candidate words of a search come in rounds of 512 slots, the bound carries
+    over from round to round and the last hit slot may lie in another round than the one being pruned (staged
+    matrix kind; beyond its 1024 spheres whatever kind the library picks, and the LDS-staged vector kind on request)."""
+    strict(renderer, rt)
+    objs, n = rt.scene("nested_glass", shells=shells)
+    w, h, spp = 96, 54, 2
+    u = rt.config_uniforms("nested_glass", w, h, spp, 60, n)
+    renderer.setupTexture(w, h)
+    want = oracle.image(u, objs, w, h)
+    for mode in (0, 2):
+        renderer.set_option(rt.RT_OPT_RESOLVE, mode)
+        try:
+            img = renderer.renderImage(u, objs, n)
+            if path is not None:
+                assert renderer.lastStats().scene_path == path
+        finally:
+            renderer.set_option(rt.RT_OPT_RESOLVE, 0)
+        assert np.array_equal(bits(img), bits(want)), mode
+    if shells == 1500:
+        renderer.set_option(rt.RT_OPT_FILTER, 2)   # vector filter, spheres staged in LDS in object order
+        renderer.set_option(rt.RT_OPT_RESOLVE, 2)
+        try:
+            img = renderer.renderImage(u, objs, n)
+            assert renderer.lastStats().scene_path == 0
+        finally:
+            strict(renderer, rt)
+        assert np.array_equal(bits(img), bits(want))
+
+
 @pytest.mark.parametrize("case", ["three_spheres", "cornell", "odd_600", "scalar_cache_1500"])
 def test_pruned_exact_pass_on_ordinary_scenes(rt, oracle, renderer, case):
     """RT_OPT_RESOLVE 2 puts every round of every scene through the bound, the bounding balls and the single-sphere prune
