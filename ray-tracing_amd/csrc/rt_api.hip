@@ -722,8 +722,14 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P, bool noalloc = false) {
     // about twice as fast as either vector kind from 1100 spheres up), or when asked for.
     // ... or staged scenes from 768 spheres up that the single frame of the staged matrix kind does not cover while
     // the tiles' frames do (measured at 1000 spheres: 71 against 52 TFLOP/s; no gain below that).
+    // ... unless rays cross many of the scene's spheres and the spheres nest (upload_scene): the kinds that keep the
+    // spheres in object order prune the candidates before the exact pass (rt_hit.hpp resolve_dense_words), the tiled
+    // kind does not (measured on 1500 nested shells: 38 Msamples*px/s through the scalar cache, 28 staged in LDS
+    // with the vector filter, 5.6 tiled).
     const bool beyond_staged = kind == 1 || (kind == 0 && (4 * P.ngroups > kMaxMatrixSpheres || ctx->nsph >= 768));
-    if (ctx->ntiles > 0 && (ctx->opt_fetch == 3 || (ctx->opt_fetch == 0 && beyond_staged && ctx->tiles_ok &&
+    const bool pruned = P.dense_kernel && ctx->opt_fetch == 0 && ctx->opt_filter == 0 && ctx->opt_resolve == 0;
+    if (pruned && kind == 0) kind = 1;
+    if (ctx->ntiles > 0 && (ctx->opt_fetch == 3 || (ctx->opt_fetch == 0 && beyond_staged && ctx->tiles_ok && !pruned &&
                                                     (ctx->opt_filter == 0 || ctx->opt_filter == 3))))
         kind = 4;
     int threads = 256, per_cu = 1;
