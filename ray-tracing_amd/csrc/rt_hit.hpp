@@ -753,9 +753,10 @@ RT_DEV bool cannot_win(f4v rec, const PruneRay &y) {
 constexpr float kBallMarginIn = 0x1p-15f, kBallMarginOut = 0x1p-8f;
 // Strikes the words whose 32 spheres cannot win as a whole (wave-uniform loop over the words that are non-empty in
 // some lane; the balls come through scalar loads, and a word about the same centre as the one before reuses the
-// ray's numbers about it).  Slots the word's balls leave out (exempt) stay.  Returns the lane's remaining non-empty
-// words.
-RT_DEV uint32_t cull_words(const float4 *word_bounds, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, const PruneRay &y) {
+// ray's numbers about it).  Slots the word's balls leave out (exempt) stay unless the single-sphere test strikes
+// them.  Returns the lane's remaining non-empty words.
+template <typename F>
+RT_DEV uint32_t cull_words(const F &f, const float4 *word_bounds, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, const PruneRay &y) {
     const const_f4_ptr balls = (const_f4_ptr)(uintptr_t)word_bounds + kBoundVec4 * (slot0 >> 5);
     uint32_t any = nz;
 #pragma unroll
@@ -775,7 +776,14 @@ RT_DEV uint32_t cull_words(const float4 *word_bounds, uint32_t *wave_masks, uint
         if (no_root_up_to_t(q, inner.x, outer.w, kBallMarginIn, kBallMarginOut, y) && ((nz >> w) & 1u)) {
             uint32_t m = 0;
             if (exempt) {
-                m = wave_masks[w * 64 + lane] & exempt;
+                // the spheres the balls leave out get the single-sphere test here (same slot for every lane), so
+                // that a lane does not keep a word for the sake of one sphere it could strike
+                uint32_t keep = exempt;
+                for (uint32_t e = exempt; e; e &= e - 1u) {
+                    const int p = 31 - __builtin_ctz(e);  // position in the word
+                    if (cannot_win(f.load1(slot0 + 32 * w + p), y)) keep &= ~(0x80000000u >> p);
+                }
+                m = wave_masks[w * 64 + lane] & keep;
                 wave_masks[w * 64 + lane] = m;
             }
             if (m == 0u) nz &= ~(1u << w);
@@ -998,7 +1006,7 @@ RT_DEV uint32_t resolve_dense_words(const F &f, const float4 *word_bounds, uint3
     // (2) ... and did the balls strike two thirds of the candidates of the lanes that came with three or more words?
     // (a word struck as a whole is taken for kDenseWordBits candidates; before in the upper half, after in the lower)
     const int words0 = __builtin_popcount(nz);
-    nz = cull_words(word_bounds, wave_masks, nz, slot0, lane, y);
+    nz = cull_words(f, word_bounds, wave_masks, nz, slot0, lane, y);
     int before, after;
     const int struck = words0 - __builtin_popcount(nz);
     nz = cull_granules(word_bounds, wave_masks, nz, slot0, lane, y, before, after);
