@@ -983,19 +983,20 @@ def test_pruned_exact_pass_over_several_rounds(rt, oracle, renderer, shells, pat
         assert np.array_equal(bits(img), bits(want))
 
 
-@pytest.mark.parametrize("case", ["three_spheres", "cornell", "odd_600", "scalar_cache_1500"])
+@pytest.mark.parametrize("case", ["three_spheres", "cornell", "odd_600", "scalar_cache_1500", "streamed_600", "lds_vector_600"])
 def test_pruned_exact_pass_on_ordinary_scenes(rt, oracle, renderer, case):
     """RT_OPT_RESOLVE 2 puts every round of every scene through the bound, the bounding balls and the single-sphere prune
     (scenes the automatic choice would never send there): a handful of objects, quads, spheres that are not numbers or
-    have radius 0, a negative radius, duplicates, an enclosing sphere; LDS-staged and scalar-cache kinds."""
-    fetch = 1 if case == "scalar_cache_1500" else 0
+    have radius 0, a negative radius, duplicates, an enclosing sphere; every kind that keeps the spheres in object order
+    (staged matrix, LDS-staged vector, scalar cache, per-wave streamed tiles)."""
+    fetch = {"scalar_cache_1500": 1, "streamed_600": 2}.get(case, 0)
     strict(renderer, rt, fetch=fetch)
     w, h, spp, depth = 96, 54, 4, 30
     if case in ("three_spheres", "cornell"):
         objs, n = rt.scene(case)
         u = rt.config_uniforms(case, w, h, spp, depth, n)
     else:
-        n0 = 580 if case == "odd_600" else 1480
+        n0 = 1480 if case == "scalar_cache_1500" else 580
         base, _ = rt.scene("random_spheres", n=n0 - 1, extent=6.0)
         glass = rt.SwiftMaterial.dielectric(1.5)
         red = rt.SwiftMaterial.lambertian(0.9, 0.1, 0.1)
@@ -1012,10 +1013,14 @@ def test_pruned_exact_pass_on_ordinary_scenes(rt, oracle, renderer, case):
         u = rt.config_uniforms("random_spheres", w, h, spp, depth, n)
     renderer.setupTexture(w, h)
     renderer.set_option(rt.RT_OPT_RESOLVE, 2)
+    if case == "lds_vector_600":
+        renderer.set_option(rt.RT_OPT_FILTER, 2)
     try:
         img = renderer.renderImage(u, objs, n)
+        path = renderer.lastStats().scene_path
     finally:
         strict(renderer, rt)
+    assert path == {"scalar_cache_1500": 1, "streamed_600": 2, "lds_vector_600": 0, "odd_600": 3}.get(case, path)
     assert np.array_equal(bits(img), bits(oracle.image(u, objs, w, h)))
 
 
