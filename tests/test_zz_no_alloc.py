@@ -82,6 +82,11 @@ def test_noalloc_entry_point_matches_rt_render_twice_in_a_row(rt):
         assert want.any() and np.array_equal(bits(got), bits(want))
         assert not want[:16].any() and not got[:16].any()  # rows above the tile stay untouched
         assert np.array_equal(bits(gi), bits(wi))
+        # third call: nested shells, i.e. the kernels that prune candidates with the scene's bounding balls
+        want, got, wi, gi, sw, sg = both_ways(rt, r, hip, "nested_glass", 160, 90, 4, 60, chunk=-1)
+        assert sg.segments == sw.segments and sg.samples == sw.samples == 160 * 90 * 4
+        assert want.any() and np.array_equal(bits(got), bits(want))
+        assert np.array_equal(bits(gi), bits(wi))
     finally:
         r.close()
 
