@@ -365,6 +365,40 @@ def test_100k_sphere_configuration_spot_pixels(rt, oracle, renderer):
     assert len(seen) > 12  # the pixels see different things: not all sky
 
 
+def test_nested_shell_configuration_spot_pixels(rt, oracle, renderer):
+    """The 400 nested glass shells at their own size -- 1920x1080, 64 spp, depth 100, default options (staged matrix
+    kind, the kernels that strike candidates before the exact pass) -- at 24 pixels, most of them on the ball, against
+    the oracle's brute-force loop, bit for bit."""
+    for opt in (rt.RT_OPT_SCENE_FETCH, rt.RT_OPT_FILTER, rt.RT_OPT_BLOCKS_PER_CU, rt.RT_OPT_RESOLVE):
+        renderer.set_option(opt, 0)
+    for opt in (rt.RT_OPT_CHUNK, rt.RT_OPT_TAIL_CHUNK, rt.RT_OPT_TAIL_SAMPLES):
+        renderer.set_option(opt, -1)
+    w, h, spp = 1920, 1080, 64
+    objs, n = rt.scene("nested_glass")
+    u = rt.config_uniforms("nested_glass", w, h, spp, 100, n)
+    renderer.setupTexture(w, h)
+    renderer.setScene(objs, n)
+    renderer.accumClear()
+    renderer.render(u, None, 0, 0, spp)
+    renderer.resolve(spp)
+    img = renderer.readTexture()
+    st = renderer.lastStats()
+    assert st.scene_path == 3 and st.samples == w * h * spp and st.tests == st.segments * n
+    assert st.segments > 15 * st.samples   # the long paths of the configuration are there
+    ranges = st.chunk_ranges(0, spp)
+    assert ranges[0][0] == 0 and ranges[-1][1] == spp and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    rng = np.random.RandomState(23)
+    pixels = [(int(rng.randint(0, w)), int(rng.randint(0, h))) for _ in range(6)]
+    pixels += [(int(rng.randint(w // 2 - 260, w // 2 + 260)), int(rng.randint(h // 2 - 260, h // 2 + 260))) for _ in range(18)]
+    sums = oracle_spot_pixels(oracle, u, objs, pixels, ranges)
+    seen = set()
+    for (x, y), acc in zip(pixels, sums):
+        want = oracle.resolve(acc.reshape(1, 1, 4), spp)[0, 0]
+        assert np.array_equal(bits(img[y, x]), bits(want)), (x, y)
+        seen.add(tuple(want))
+    assert len(seen) > 12
+
+
 def test_4k_cover_per_rank_share_spot_pixels(rt, oracle, renderer):
     """The 3840x2160 x 1000 spp cover configuration as one rank of eight traces it: all pixels, the sample indices
     ray_range(rank, 8, 1000), default options, for the first and the last rank; 16 scattered pixels' linear sums each
