@@ -25,6 +25,7 @@ struct WfPool {
     float4 *rec;            // [slots][kSlotVec4]
                             // meta: px | py << 16, chunk, next rayIndex, end rayIndex
     int *depth;             // bounces done; < 0: the slot holds no item
+    int *hint;              // sphere slot the slot's path hit last (Work::last_slot of the kernels that prune candidates)
     uint32_t *q_ext[2];     // slots with a live ray, ping-pong
     uint32_t *q_mat[3];     // slots to shade: lambertian (and unknown kinds), metal, dielectric
     uint32_t *q_gen;        // slots whose sample finished
@@ -166,7 +167,8 @@ __global__ __launch_bounds__(256) void wf_generate_kernel(const TraceParams P, c
 }
 
 // Each workgroup stages the scene once and then takes batches of blockDim.x queue entries in a grid-stride loop.
-template <int KIND>
+// DENSE: the instantiation with the pruning exact pass (scenes whose rays cross many nested spheres, rt_hit.hpp).
+template <int KIND, bool DENSE>
 __global__ __launch_bounds__(KIND == kFetchMatrix ? 1024 : 256) void wf_extend_kernel(const TraceParams P, const WfPool W, int cur) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_words[];
     const uint32_t n = W.cnt[cur];
@@ -185,7 +187,11 @@ __global__ __launch_bounds__(KIND == kFetchMatrix ? 1024 : 256) void wf_extend_k
         Hit hit;
         float t;
         Prof<false> prof;
-        int obj = world_hit(P, fetch, wave_masks, active, o, d, hit, t, prof, work);
+        if constexpr (DENSE) work.last_slot = W.hint[slot];
+        int obj = world_hit<Fetch<KIND>, false, DENSE>(P, fetch, wave_masks, active, o, d, hit, t, prof, work);
+        if constexpr (DENSE) {
+            if (active) W.hint[slot] = work.last_slot;
+        }
         bool miss = active && obj < 0;
         int kind = -1;
         if (active && obj >= 0) {
@@ -265,8 +271,8 @@ __global__ void wf_rotate_kernel(uint32_t *cnt, int cur) {
 // ---- host side -------------------------------------------------------------------------------------------
 
 size_t wavefront_pool_bytes(int slots) {
-    // 7 float4 + 1 int4 + 1 int + 6 queues of uint32 per slot, plus the counters
-    return (size_t)slots * (8 * 16 + 4 + 6 * 4) + 256;
+    // 7 float4 + 1 int4 + 2 int + 6 queues of uint32 per slot, plus the counters
+    return (size_t)slots * (8 * 16 + 2 * 4 + 6 * 4) + 256;
 }
 
 static WfPool carve_pool(void *base, int slots) {
@@ -276,6 +282,7 @@ static WfPool carve_pool(void *base, int slots) {
     W.cnt = (uint32_t *)take(256);
     W.rec = (float4 *)take((size_t)slots * 16 * kSlotVec4);
     W.depth = (int *)take((size_t)slots * 4);
+    W.hint = (int *)take((size_t)slots * 4);
     W.q_ext[0] = (uint32_t *)take((size_t)slots * 4);
     W.q_ext[1] = (uint32_t *)take((size_t)slots * 4);
     W.q_mat[0] = (uint32_t *)take((size_t)slots * 4);
@@ -298,26 +305,26 @@ hipError_t run_wavefront(const TraceParams &P, int fetch_kind, int extend_thread
     const int ext_blocks = extend_blocks > 0 && extend_blocks < ext_need ? extend_blocks : ext_need;
     hipError_t e = hipMemsetAsync(W.cnt, 0, 256, stream);
     if (e != hipSuccess) return e;
+    if (e == hipSuccess) e = hipMemsetAsync(W.hint, 0, (size_t)slots * 4, stream);
+    if (e != hipSuccess) return e;
     const size_t lds = trace_lds_bytes(P, fetch_kind, extend_threads);
+    const bool dense = P.dense_kernel != 0;
+    typedef void (*extend_fn)(const TraceParams, const WfPool, int);
+    const extend_fn extend = fetch_kind == kFetchMatrix ? (dense ? wf_extend_kernel<kFetchMatrix, true> : wf_extend_kernel<kFetchMatrix, false>)
+                             : fetch_kind == kFetchLds  ? (dense ? wf_extend_kernel<kFetchLds, true> : wf_extend_kernel<kFetchLds, false>)
+                                                        : (dense ? wf_extend_kernel<kFetchScalar, true> : wf_extend_kernel<kFetchScalar, false>);
     if (lds > 64 * 1024) {
-        const void *fn = fetch_kind == kFetchMatrix ? (const void *)wf_extend_kernel<kFetchMatrix>
-                         : fetch_kind == kFetchLds  ? (const void *)wf_extend_kernel<kFetchLds>
-                                                    : (const void *)wf_extend_kernel<kFetchScalar>;
-        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute((const void *)extend, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
+    const int ext_threads = fetch_kind == kFetchMatrix ? extend_threads : 256;
     int cur = 0;
     hipLaunchKernelGGL(wf_generate_kernel, dim3(blocks), dim3(256), 0, stream, P, W, cur, 1);
     int steps = 0;
     if (!host_cnt) return hipErrorInvalidValue;
     for (;;) {
         const int next = cur ^ 1;
-        if (fetch_kind == kFetchMatrix)
-            hipLaunchKernelGGL(wf_extend_kernel<kFetchMatrix>, dim3(ext_blocks), dim3(extend_threads), lds, stream, P, W, cur);
-        else if (fetch_kind == kFetchLds)
-            hipLaunchKernelGGL(wf_extend_kernel<kFetchLds>, dim3(ext_blocks), dim3(256), lds, stream, P, W, cur);
-        else
-            hipLaunchKernelGGL(wf_extend_kernel<kFetchScalar>, dim3(ext_blocks), dim3(256), lds, stream, P, W, cur);
+        hipLaunchKernelGGL(extend, dim3(ext_blocks), dim3(ext_threads), lds, stream, P, W, cur);
         hipLaunchKernelGGL(wf_shade_kernel, dim3(blocks), dim3(256), 0, stream, P, W, next);
         hipLaunchKernelGGL(wf_generate_kernel, dim3(blocks), dim3(256), 0, stream, P, W, next, 0);
         hipLaunchKernelGGL(wf_rotate_kernel, dim3(1), dim3(64), 0, stream, W.cnt, cur);
