@@ -209,12 +209,21 @@ __global__ __launch_bounds__(KIND == kFetchMatrix ? 1024 : 256) void wf_extend_k
         block_push(bp, 4, miss ? 3 : kind, slot);
         nseg += active ? 1 : 0;
     }
+    // segments and executed-work counters: summed over the workgroup in LDS, one global atomic each per workgroup (a
+    // bounce step launches thousands of waves, and their atomics would all go to the same three addresses)
     for (int off = 32; off > 0; off >>= 1) nseg += __shfl_down(nseg, off, 64);
-    if ((threadIdx.x & 63) == 0 && nseg) atomicAdd(P.seg_counter, (unsigned long long)nseg);
+    __shared__ unsigned long long s_sum[3];
+    if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
+    __syncthreads();
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(P.seg_counter + 9, (unsigned long long)work.trips);
-        atomicAdd(P.seg_counter + 10, (unsigned long long)work.blocks);
+        if (nseg) atomicAdd(&s_sum[0], (unsigned long long)nseg);
+        atomicAdd(&s_sum[1], (unsigned long long)work.trips);
+        atomicAdd(&s_sum[2], (unsigned long long)work.blocks);
     }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_sum[0]) atomicAdd(P.seg_counter, s_sum[0]);
+    if (threadIdx.x == 1) atomicAdd(P.seg_counter + 9, s_sum[1]);
+    if (threadIdx.x == 2) atomicAdd(P.seg_counter + 10, s_sum[2]);
 }
 
 __global__ __launch_bounds__(256) void wf_shade_kernel(const TraceParams P, const WfPool W, int next) {
