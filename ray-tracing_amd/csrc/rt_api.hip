@@ -753,6 +753,11 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P, bool noalloc = false) {
     long long need = ((long long)P.nitems + 63) / 64;
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
+    // ... and with workgroups no larger than the items can fill: a wave without an item exits at once, and which
+    // waves those are is left to chance, so big workgroups would leave some SIMDs with four busy waves and others
+    // with none (the staged matrix kind runs with 256, 512 or 1024 threads)
+    if (kind == 3 && ctx->opt_kernel != 1)
+        while (threads > 256 && blocks * (threads / 64) >= 2 * need) threads /= 2;
     uint32_t *counters = ctx->counters;
     if (noalloc) {
         if (ctx->opt_kernel == 1)
