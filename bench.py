@@ -300,7 +300,7 @@ def main():
             "valu_design_point": valu,
         })
         out = {
-            "metric": "Msamples*px/s (whole job), RTiOW cover 1080p; % FP32 VALU peak",
+            "metric": "Msamples*px/s (whole job), RTiOW cover 1080p; roofline: fraction of the dense FP16 matrix peak (default kernel) and of the FP32 VALU peak (vector design point)",
             "value": total_samples / (ms_per_step * 1e-3) * 1e-6,
             "unit": "Msamples*px/s",
             "n_gpus": world,

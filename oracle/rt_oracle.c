@@ -673,3 +673,34 @@ RTO_API void rto_present_bgra8(const float *tex, int tex_w, int tex_h, uint8_t *
         }
     }
 }
+
+/* pow(1 - cosine, 5) of Lib.metal:180 is C powf here; the HIP kernel forms the same power as a binary64 product
+ * rounded once to binary32, (float)((x*x) * (x*x) * x) with x widened first.  This sweeps every binary32 in
+ * [bits_lo, bits_hi] (bit patterns of non-negative floats) through both and returns how many results differ;
+ * first_diff (optional) receives the bit pattern of the lowest differing argument, max_ulp (optional) the largest
+ * difference in units of the last place. */
+RTO_API uint64_t rto_pow5_sweep(uint32_t bits_lo, uint32_t bits_hi, uint32_t *first_diff, uint32_t *max_ulp) {
+    uint64_t ndiff = 0;
+    uint32_t first = 0xFFFFFFFFu, worst = 0;
+#pragma omp parallel for schedule(static) reduction(+ : ndiff) reduction(min : first) reduction(max : worst)
+    for (int64_t i = (int64_t)bits_lo; i <= (int64_t)bits_hi; ++i) {
+        uint32_t b = (uint32_t)i;
+        float x;
+        memcpy(&x, &b, sizeof x);
+        float a = powf(x, 5.0f);
+        double p = (double)x, p2 = p * p;
+        float g = (float)(p2 * p2 * p);
+        uint32_t ab, gb;
+        memcpy(&ab, &a, sizeof ab);
+        memcpy(&gb, &g, sizeof gb);
+        if (ab != gb) {
+            ++ndiff;
+            if (b < first) first = b;
+            uint32_t d = ab > gb ? ab - gb : gb - ab;
+            if (d > worst) worst = d;
+        }
+    }
+    if (first_diff) *first_diff = first;
+    if (max_ulp) *max_ulp = worst;
+    return ndiff;
+}

@@ -88,6 +88,7 @@ struct rt_ctx {
     unsigned long long launches = 0;    // trace launches so far
     unsigned long long times_read = 0;  // launches already reported by rt_trace_times
     bool stats_pending = false;
+    bool stats_timed = false;  // the pending launch was bracketed by timing events (not when it was captured into a graph)
 
     int opt_chunk = -1, opt_tail_chunk = -1, opt_tail_samples = -1;
     int opt_kernel = 0;
@@ -486,14 +487,18 @@ bool balls_nested(const std::vector<float4> &balls) {
     return groups > 0 && 2 * nested >= groups;
 }
 
-int upload_scene(rt_ctx *ctx, const Object *objs, int n) {
+// cache_hit (optional): set when the bytes equal the last upload and the device arrays were kept as they are.
+int upload_scene(rt_ctx *ctx, const Object *objs, int n, bool *cache_hit = nullptr) {
+    if (cache_hit) *cache_hit = false;
     if (n < 0 || (n > 0 && !objs)) return fail(ctx, RT_ERR_INVALID, "rt: bad object array");
     // The reference re-sends its objects with every dispatch (ContentView.swift:689-696), and so may callers of
     // rt_render_tile: 510 times per pass over a 1080p target.  The bytes are compared with those the device arrays
     // were built from, and the compaction, lifting, tiling and uploads below are skipped when nothing changed.
     const size_t nbytes = (size_t)n * sizeof(Object);
-    if (ctx->uploaded_valid && ctx->uploaded.size() == nbytes && (nbytes == 0 || std::memcmp(ctx->uploaded.data(), objs, nbytes) == 0))
+    if (ctx->uploaded_valid && ctx->uploaded.size() == nbytes && (nbytes == 0 || std::memcmp(ctx->uploaded.data(), objs, nbytes) == 0)) {
+        if (cache_hit) *cache_hit = true;
         return RT_OK;
+    }
     ctx->uploaded_valid = false;
     std::vector<float4> sph;
     std::vector<int> sph_obj;
@@ -654,12 +659,13 @@ int scene_for_call(rt_ctx *ctx, const Uniforms *u, const Object *objs, int objCo
     if (objs) {
         if (u->objCount < 0 || u->objCount > objCount)
             return fail(ctx, RT_ERR_INVALID, "rt: uniforms.objCount must be within [0, objCount]");
-        const bool same = ctx->uploaded_valid && ctx->uploaded.size() == (size_t)u->objCount * sizeof(Object);
         const bool was_resident = ctx->scene_resident;
         ctx->scene_resident = false;
-        RT_TRY(upload_scene(ctx, objs, u->objCount));
-        // a call that re-sends exactly the resident scene leaves it resident
-        if (same && was_resident && ctx->uploaded_valid) ctx->scene_resident = true;
+        bool same = false;
+        RT_TRY(upload_scene(ctx, objs, u->objCount, &same));
+        // a call that re-sends exactly the resident scene (same bytes: the device arrays were kept) leaves it resident;
+        // any other scene replaces it, and a later objs == NULL call fails until rt_set_scene is called again
+        if (same && was_resident) ctx->scene_resident = true;
         return RT_OK;
     }
     if (!ctx->scene_resident) return fail(ctx, RT_ERR_NO_SCENE, "rt: objs is NULL and no scene was set with rt_set_scene");
@@ -769,6 +775,12 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P, bool noalloc = false) {
         P.seg_counter = (unsigned long long *)(counters + 2);
     }
     ctx->stats_src = counters;
+    // A stream that is being captured into a HIP graph records no timing events: an event recorded under capture has no
+    // time of its own, and hipEventElapsedTime on it fails.  The launch is then not counted by rt_trace_times, and
+    // rt_last_stats (after the graph has run) reports its counters with kernel_ms = 0.
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &capture) != hipSuccess) capture = hipStreamCaptureStatusNone;
+    const bool timed = capture == hipStreamCaptureStatusNone;
     RT_HIP(hipMemsetAsync(counters, 0, 256, ctx->stream));
     const int slot = (int)(ctx->launches % rt_ctx::kRing);
     int path = kind;  // what rt_stats reports
@@ -778,6 +790,7 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P, bool noalloc = false) {
             return fail(ctx, RT_ERR_TOO_LARGE, "rt: the wavefront kernels pack pixel coordinates in 16 bits");
         long long slots = ((long long)P.nitems + 255) / 256 * 256;
         if (slots > ctx->opt_wf_slots) slots = ctx->opt_wf_slots;
+        if (!timed) return fail(ctx, RT_ERR_INVALID, "rt: the wavefront formulation reads its queue counters on the host between steps and cannot be captured into a graph");
         RT_TRY(grow(ctx, ctx->wf_pool, wavefront_pool_alloc_bytes((int)slots)));
         RT_HIP(hipEventRecord(ctx->ev0[slot], ctx->stream));
         int steps = 0;
@@ -794,12 +807,13 @@ int enqueue_trace(rt_ctx *ctx, TraceParams &P, bool noalloc = false) {
             RT_TRY(grow(ctx, ctx->rayq, (size_t)blocks * threads * kQueueRays * 2));
             P.rayq = ctx->rayq.ptr;
         }
-        RT_HIP(hipEventRecord(ctx->ev0[slot], ctx->stream));
+        if (timed) RT_HIP(hipEventRecord(ctx->ev0[slot], ctx->stream));
         RT_HIP(launch_trace(P, kind, ctx->opt_kernel == 2, (int)blocks, threads, ctx->stream));
-        RT_HIP(hipEventRecord(ctx->ev1[slot], ctx->stream));
+        if (timed) RT_HIP(hipEventRecord(ctx->ev1[slot], ctx->stream));
     }
-    ctx->launches++;
+    if (timed) ctx->launches++;
     ctx->stats_pending = true;
+    ctx->stats_timed = timed;
     ctx->last = {};
     ctx->last.grid_blocks = (int)blocks;
     ctx->last.block_threads = ctx->opt_kernel == 1 ? 256 : threads;
@@ -1232,8 +1246,10 @@ RT_API int rt_last_stats(rt_ctx *ctx, rt_stats *out) {
     if (ctx->stats_pending) {
         RT_HIP(hipStreamSynchronize(ctx->stream));
         float ms = 0.0f;
-        const int slot = (int)((ctx->launches - 1) % rt_ctx::kRing);
-        RT_HIP(hipEventElapsedTime(&ms, ctx->ev0[slot], ctx->ev1[slot]));
+        if (ctx->stats_timed) {
+            const int slot = (int)((ctx->launches - 1) % rt_ctx::kRing);
+            RT_HIP(hipEventElapsedTime(&ms, ctx->ev0[slot], ctx->ev1[slot]));
+        }
         uint32_t host[24] = {0};
         RT_HIP(hipMemcpyAsync(host, ctx->stats_src ? ctx->stats_src : ctx->counters, sizeof host, hipMemcpyDeviceToHost, ctx->stream));
         RT_HIP(hipStreamSynchronize(ctx->stream));

@@ -443,12 +443,16 @@ RT_DEV void lift_ray_near(const LiftFrame &F, float cmax, V3 o, V3 dn, float sla
 // Pass A on the matrix cores over 64-sphere blocks [blk0, blk1): same candidate words as filter_round.
 //
 // The four matrix instructions of a 32-sphere group are issued back to back and fenced off from the vector code
-// on both sides with scheduling barriers.  Letting the compiler weave the sign extraction of one group between
-// the matrix instructions of the next gave results that changed from run to run on MI355X (ROCm 7.2 compiler;
-// caught by rt_selftest_matrix_filter: its reference-side counts drift by a few hundred pairs in 3e8 although the
-// filter's own counts stay fixed; either barrier alone removes it, the cause was not isolated), so nothing but
-// matrix instructions is in flight between the barriers, and the results are read only after the whole group has
-// been issued.  -DRT_NO_MFMA_FENCE=0 builds without them, to reproduce.
+// on both sides with scheduling barriers, and the results are read only after the whole group has been issued, in
+// ascending register order.  The reason: MI355X does not interlock a vector read of a matrix result.  The 16 result
+// registers of v_mfma_f32_32x32x16_f16 are written four at a time, register r being safe to read 5 + ceil(r / 2)
+// wait states after issue (5 for r = 0, 12 for r = 13..15); an earlier read silently returns the old contents
+// (tools/mfma_hazard_probe.hip).  The ROCm 7.2 compiler spaces such reads by 11 wait states, one short for the last
+// three registers unless another wave stretches the distance -- which showed as counts of rt_selftest_matrix_filter
+// that drifted from run to run when the compiler was left to weave the sign extraction of one group between the
+// matrix instructions of the next.  With the group fenced and read in order every read is at least 6 wait states
+// beyond the requirement; tools/check_mfma_distance.py proves that on the compiled ISA of every kernel (it runs in
+// the CPU tests).  -DRT_NO_MFMA_FENCE=0 builds without the barriers.
 RT_DEV void matrix_group(const h8 a_lo, const h8 a_hi, const RayLifted &L, f32x16 &q0, f32x16 &q1) {
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #if !defined(RT_NO_MFMA_FENCE) || (RT_NO_MFMA_FENCE & 1)
@@ -598,13 +602,19 @@ RT_DEV void resolve_balanced(const F &f, uint32_t *wave_masks, uint32_t nz, int 
 // are in flight at a time -- the two highest and the two lowest set bits of the current word -- and their code has
 // no branches: every lane runs the same instructions anyway.  Four at once is possible because the root a sphere
 // offers does not depend on the best distance so far (see resolve_balanced), so the lane's answer is the minimum
-// over (distance, slot) in any visiting order; the running best only serves to discard numerators above its own
-// ("not above" in place of the reference's "below", so that an equal distance at a lower slot is still seen).  When
+// over (distance, slot) in any visiting order; the running best only serves to discard numerators clearly above its
+// own (LaneBest::prune_above: an equal distance at a lower slot must still be seen, and it can come from a numerator
+// a few ulps larger).  When
 // a word has fewer than four bits left some chains resolve the same candidate twice, which changes nothing.
 struct LaneBest {
     float t;        // smallest accepted root so far (tbest on entry)
     uint32_t slot;  // its slot, 0xFFFFFFFF while none
     float n;        // its numerator (root * a up to rounding); +inf while none was found in this call
+    // Numerator up to which a candidate is still looked at.  Two numerators a few ulps apart can give the same
+    // correctly rounded quotient by a, and an equal root at a lower slot must win (Shaders.metal:21 keeps the first of
+    // equal distances), so the cut is not best.n itself but best.n (1 + 2^-22): four ulps, from where the quotients
+    // by the same a can no longer coincide (the same allowance as sphere_root_any_order's nskip).
+    RT_DEV float prune_above() const { return n * (1.0f + 0x1p-22f); }
 };
 struct LaneRoot {
     bool ok, retry;  // retry: the first root exists but is not above kTMin, so the second has to be looked at
@@ -661,7 +671,7 @@ RT_DEV void resolve_word_per_lane(const F &f, uint32_t m, int base, V3 o, V3 d, 
             prof.count(6);
             prof.count(7, (uint64_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) * 4);
         }
-        const float nprune = best.n;
+        const float nprune = best.prune_above();
         // all four records are asked for before the first is used (the statement below keeps the reads together)
         f4v c0 = f.load1(base + p0), c1 = f.load1(base + p1), c2 = f.load1(base + p2), c3 = f.load1(base + p3);
         asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
@@ -912,8 +922,8 @@ RT_DEV uint32_t resolve_rest_per_lane(const F &f, const uint32_t *wave_masks, ui
         }
         f4v c0 = f.load1(s[0]), c1 = f.load1(s[1]), c2 = f.load1(s[2]), c3 = f.load1(s[3]);
         asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
-        const float none = -__builtin_inff();
-        const float n0 = v[0] ? best.n : none, n1 = v[1] ? best.n : none, n2 = v[2] ? best.n : none, n3 = v[3] ? best.n : none;
+        const float none = -__builtin_inff(), upto = best.prune_above();
+        const float n0 = v[0] ? upto : none, n1 = v[1] ? upto : none, n2 = v[2] ? upto : none, n3 = v[3] ? upto : none;
         const LaneRoot r0 = lane_root(c0, o, d, dv, n0), r1 = lane_root(c1, o, d, dv, n1);
         const LaneRoot r2 = lane_root(c2, o, d, dv, n2), r3 = lane_root(c3, o, d, dv, n3);
         lane_offer(best, r0, (uint32_t)s[0]);
@@ -986,7 +996,7 @@ RT_DEV uint32_t resolve_dense_words(const F &f, const float4 *word_bounds, uint3
         const int s0 = k[0] >= 0 ? k[0] : (on ? any_k : slot0), s1 = k[1] >= 0 ? k[1] : s0, s2 = k[2] >= 0 ? k[2] : s0, s3 = k[3] >= 0 ? k[3] : s2;
         f4v c0 = f.load1(s0), c1 = f.load1(s1), c2 = f.load1(s2), c3 = f.load1(s3);
         asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
-        const float nprune = on ? best.n : -__builtin_inff();  // a lane without candidates accepts nothing
+        const float nprune = on ? best.prune_above() : -__builtin_inff();  // a lane without candidates accepts nothing
         const LaneRoot r0 = lane_root(c0, o, d, dv, nprune), r1 = lane_root(c1, o, d, dv, nprune);
         const LaneRoot r2 = lane_root(c2, o, d, dv, nprune), r3 = lane_root(c3, o, d, dv, nprune);
         lane_offer(best, r0, (uint32_t)s0);

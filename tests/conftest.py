@@ -52,6 +52,8 @@ class Oracle:
         lib.rto_resolve.argtypes = [vp, ip, ip, vp]
         lib.rto_present_bgra8.restype = None
         lib.rto_present_bgra8.argtypes = [vp, ip, ip, vp, ip, ip]
+        lib.rto_pow5_sweep.restype = C.c_uint64
+        lib.rto_pow5_sweep.argtypes = [u32, u32, vp, vp]
         self.lib = lib
 
     def image(self, u, objs, w, h, tex=None, reference_grid=0, stats=None):

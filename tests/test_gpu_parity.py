@@ -275,6 +275,37 @@ def test_full_size_cover_spot_pixels(rt, oracle, renderer):
     assert np.isfinite(img1).all() and img1.min() >= 0 and img1.max() <= 1 and (img1[..., 3] == 1).all()
 
 
+def test_cover_1200x675_at_its_own_500_spp_spot_pixels(rt, oracle, renderer):
+    """The 1200x675 cover configuration at the sample count it is specified with (500 spp, depth 50, default options;
+    rayIndex enters the seed, Shaders.metal:121-126): 32 scattered pixels, each chunk's sequential sum, the chunks added
+    in order, mean and gamma recomputed by the oracle, bit for bit."""
+    for opt in (rt.RT_OPT_SCENE_FETCH, rt.RT_OPT_FILTER, rt.RT_OPT_BLOCKS_PER_CU, rt.RT_OPT_RESOLVE):
+        renderer.set_option(opt, 0)
+    for opt in (rt.RT_OPT_CHUNK, rt.RT_OPT_TAIL_CHUNK, rt.RT_OPT_TAIL_SAMPLES):
+        renderer.set_option(opt, -1)
+    w, h, spp = 1200, 675, 500
+    objs, n = rt.scene("cover")
+    u = rt.config_uniforms("cover", w, h, spp, 50, n)
+    renderer.setupTexture(w, h)
+    renderer.setScene(objs, n)
+    renderer.accumClear()
+    renderer.render(u, None, 0, 0, spp)
+    renderer.resolve(spp)
+    img = renderer.readTexture()
+    st = renderer.lastStats()
+    assert st.scene_path == 3 and st.samples == w * h * spp
+    ranges = st.chunk_ranges(0, spp)
+    assert ranges[0][0] == 0 and ranges[-1][1] == spp and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    rng = np.random.RandomState(29)
+    pixels = [(int(rng.randint(0, w)), int(rng.randint(0, h))) for _ in range(32)]
+    seen = set()
+    for (x, y), acc in zip(pixels, oracle_spot_pixels(oracle, u, objs, pixels, ranges)):
+        want = oracle.resolve(acc.reshape(1, 1, 4), spp)[0, 0]
+        assert np.array_equal(bits(img[y, x]), bits(want)), (x, y)
+        seen.add(tuple(want))
+    assert len(seen) > 16
+
+
 def test_bench_configuration_spot_pixels(rt, oracle, renderer):
     """The configuration bench.py times -- cover scene, 1920x1080, 1000 spp, depth 50, default options (matrix-core
     filter, automatic work items) -- at 32 scattered pixels: each chunk's sequential sum, the chunks added in order,
@@ -880,6 +911,41 @@ def test_exact_pass_forms_bit_exact(rt, oracle, renderer, name, w, h, spp, depth
         finally:
             renderer.set_option(rt.RT_OPT_RESOLVE, 0)
         assert np.array_equal(bits(img), bits(want)), mode
+
+
+def test_lane_by_lane_exact_pass_on_overlapping_spheres(rt, oracle, renderer):
+    """Spheres that overlap pairwise without being duplicates (a ray through the circle in which two of them meet gets
+    the same distance from both, possibly from numerators a few ulps apart: the lower object index must win,
+    Shaders.metal:17-22), diffuse, so that bounced rays have unnormalised directions (Lib.metal:158-164) -- resolved
+    lane by lane (RT_OPT_RESOLVE 2), pooled (1) and automatically, against the oracle, images and first hits."""
+    rng = np.random.RandomState(41)
+    objs_l = []
+    for i in range(120):
+        c = rng.uniform(-0.6, 0.6, 3) + np.array([0.0, 0.0, -1.0])   # around the point the three-sphere camera looks at
+        rad = float(rng.uniform(0.12, 0.25))
+        mat = rt.SwiftMaterial.lambertian(*rng.uniform(0.2, 0.9, 3)) if i % 3 else rt.SwiftMaterial.dielectric(1.5)
+        objs_l.append(rt.makeSphere(tuple(float(v) for v in c), rad, mat))
+        # a partner that cuts it in a circle facing the camera
+        c2 = c + rng.uniform(-0.08, 0.08, 3) + float(rng.uniform(0.02, 0.08)) * np.array([-2.0, 2.0, 2.0]) / 12.0 ** 0.5
+        objs_l.append(rt.makeSphere(tuple(float(v) for v in c2), rad * float(rng.uniform(0.8, 1.1)), rt.SwiftMaterial.metal(0.8, 0.7, 0.6, 0.1)))
+    objs, n = rt.object_array(objs_l), len(objs_l)
+    w, h, spp = 200, 150, 8
+    u = rt.config_uniforms("three_spheres", w, h, spp, 12, n)
+    renderer.setupTexture(w, h)
+    want = oracle.image(u, objs, w, h)
+    want4, want_ids = oracle.first_hit(u, objs, w, h)
+    assert len(np.unique(want_ids)) > 40
+    try:
+        for mode in (2, 1, 0):
+            strict(renderer, rt)
+            renderer.set_option(rt.RT_OPT_FILTER, 3)   # the staged matrix kind whatever the sphere count
+            renderer.set_option(rt.RT_OPT_RESOLVE, mode)
+            img = renderer.renderImage(u, objs, n)
+            assert np.array_equal(bits(img), bits(want)), mode
+            t4, ids = renderer.firstHit(u, objs, n)
+            assert np.array_equal(ids, want_ids) and np.array_equal(bits(t4), bits(want4)), mode
+    finally:
+        strict(renderer, rt)
 
 
 def _dense_scene(rt, kind):

@@ -116,3 +116,64 @@ def test_noalloc_entry_point_limits(rt):
         assert np.array_equal(bits(got), bits(want)) and np.array_equal(bits(gi), bits(wi))
     finally:
         r.close()
+
+
+def test_noalloc_entry_point_under_graph_capture(rt):
+    """The caller the entry point names first: rt_accum_clear + rt_render_noalloc + rt_resolve captured into a HIP graph
+    on the context's stream (global capture mode, which refuses allocating calls), the graph launched twice, buffers
+    dirtied in between; sums and image bit-identical to rt_render outside a graph."""
+    hip = hip_runtime()
+    vp = C.c_void_p
+    hip.hipStreamCreate.argtypes = [C.POINTER(vp)]
+    hip.hipStreamDestroy.argtypes = [vp]
+    hip.hipStreamBeginCapture.argtypes = [vp, C.c_int]
+    hip.hipStreamEndCapture.argtypes = [vp, C.POINTER(vp)]
+    hip.hipGraphInstantiate.argtypes = [C.POINTER(vp), vp, vp, vp, C.c_size_t]
+    hip.hipGraphLaunch.argtypes = [vp, vp]
+    hip.hipGraphExecDestroy.argtypes = [vp]
+    hip.hipGraphDestroy.argtypes = [vp]
+    hip.hipMemset.argtypes = [vp, C.c_int, C.c_size_t]
+    stream = vp()
+    assert hip.hipStreamCreate(C.byref(stream)) == 0
+    r = rt.MetalRenderer(device=0, stream=stream.value)
+    graph, gexec = vp(), vp()
+    try:
+        w, h, spp = 320, 180, 24
+        objs, n = rt.scene("cover")
+        u = rt.config_uniforms("cover", w, h, spp, 50, n)
+        r.setupTexture(w, h)
+        r.setScene(objs, n)
+        r.set_option(rt.RT_OPT_CHUNK, -1)
+        r.accumClear()
+        r.render(u, None, 0, 0, spp)
+        want = accum_of(r, hip, w, h)
+        r.resolve(spp)
+        want_img = r.readTexture()
+        segments = r.lastStats().segments
+        r.synchronize()
+        assert hip.hipStreamBeginCapture(stream, 0) == 0  # hipStreamCaptureModeGlobal
+        try:
+            r.accumClear()
+            r.renderNoAlloc(u, 0, spp)
+            r.resolve(spp)
+        finally:
+            rc = hip.hipStreamEndCapture(stream, C.byref(graph))
+        assert rc == 0 and graph.value
+        assert hip.hipGraphInstantiate(C.byref(gexec), graph, None, None, 0) == 0
+        for rep in range(2):
+            assert hip.hipMemset(r.accumPtr(), 0x7F, w * h * 16) == 0   # whatever the last run left must not matter
+            r.clearTexture()
+            r.synchronize()
+            assert hip.hipGraphLaunch(gexec, stream) == 0
+            got = accum_of(r, hip, w, h)
+            assert np.array_equal(bits(got), bits(want)), rep
+            assert np.array_equal(bits(r.readTexture()), bits(want_img)), rep
+        st = r.lastStats()   # counters of the graph's launch; no timing events were recorded under capture
+        assert st.segments == segments and st.kernel_ms == 0.0
+    finally:
+        if gexec.value:
+            hip.hipGraphExecDestroy(gexec)
+        if graph.value:
+            hip.hipGraphDestroy(graph)
+        r.close()
+        hip.hipStreamDestroy(stream)
