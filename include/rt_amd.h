@@ -79,12 +79,16 @@ enum {
                                tail (measured on the cover scene: it costs more in camera-ray generation than the
                                even drain gains) */
     RT_OPT_TAIL_SAMPLES = 9, /* samples per pixel in that tail; -1 (default) = automatic */
-    RT_OPT_RESOLVE = 10     /* how the exact hit test walks the candidates the sphere filter left (LDS-staged scenes;
+    RT_OPT_RESOLVE = 10,    /* how the exact hit test walks the candidates the sphere filter left (LDS-staged scenes;
                                results are identical): 0 = automatic (default): pooled over the wave, and for scenes
                                whose lines cross many spheres (nested shells; decided at scene upload) candidates that
                                cannot win are struck first (bounding balls per 32 and 8 consecutive spheres, then a
                                test per sphere) and dense candidate words go lane by lane, four candidates in flight;
                                1 = always pooled; 2 = always struck and lane by lane */
+    RT_OPT_REGROUP = 11     /* material scatter of the staged matrix kind's batch kernels (results are identical):
+                               0 = automatic (default), 1 = every lane scatters its own path, 2 = requests are sorted by
+                               material over the workgroup through LDS, so that a wave runs one branch of the material
+                               code; the waves of a workgroup then take every trip of the main loop together */
 };
 
 /* setupMetal (ContentView.swift:328-356): device, queue, pipelines.  `device` is the HIP device ordinal.

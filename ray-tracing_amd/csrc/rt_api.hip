@@ -96,6 +96,7 @@ struct rt_ctx {
     int opt_blocks_per_cu = 0;
     int opt_filter = 0;
     int opt_resolve = 0;
+    int opt_regroup = 0;
     int opt_wf_slots = 1 << 20;
 
     rt_stats last = {};
@@ -520,6 +521,13 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n, bool *cache_hit = nullp
         m.fuzz = o.mat.reflection_fuzz;
         m.ior = o.mat.refraction_index;
         m.inv_ior = 1.0f / o.mat.refraction_index;  // Lib.metal:185
+        if (m.type == DIELECTRIC) {
+            // Lib.metal:178-179 for the two values refraction_index takes there (Lib.metal:185); a dielectric's albedo is
+            // never read (its attenuation is 1, Lib.metal:184), so its slots carry them
+            volatile float rf = (1.0f - m.inv_ior) / (1.0f + m.inv_ior), rb = (1.0f - m.ior) / (1.0f + m.ior);
+            m.albedo.x = rf * rf;
+            m.albedo.y = rb * rb;
+        }
         mats[(size_t)i] = m;
         if (o.type == TYPE_SPHERE) {
             sph.push_back(make_float4(o.s.center.x, o.s.center.y, o.s.center.z, o.s.radius));  // strict record
@@ -700,6 +708,7 @@ void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
     P.lift = ctx->lift;
     P.nobj = ctx->nobj;
     P.resolve_mode = ctx->opt_resolve;
+    P.regroup = ctx->opt_regroup == 2 && ctx->opt_kernel != 1 ? 1 : 0;
     P.dense_kernel = ctx->opt_resolve == 2 || (ctx->opt_resolve == 0 && ctx->scene_dense) ? 1 : 0;
     P.width = ctx->width;
     P.height = ctx->height;
@@ -931,6 +940,10 @@ RT_API int rt_set_option(rt_ctx *ctx, int key, int value) {
             if (value < 0 || value > 2) return fail(ctx, RT_ERR_INVALID, "rt: resolve form must be 0, 1 or 2");
             ctx->opt_resolve = value;
             return RT_OK;
+        case RT_OPT_REGROUP:
+            if (value < 0 || value > 2) return fail(ctx, RT_ERR_INVALID, "rt: regroup must be 0, 1 or 2");
+            ctx->opt_regroup = value;
+            return RT_OK;
         case RT_OPT_WAVEFRONT_SLOTS:
             if (value < 256 || value > (1 << 24)) return fail(ctx, RT_ERR_INVALID, "rt: wavefront slots out of range");
             ctx->opt_wf_slots = value / 256 * 256;
@@ -950,6 +963,7 @@ RT_API int rt_get_option(const rt_ctx *ctx, int key, int *value) {
         case RT_OPT_BLOCKS_PER_CU: *value = ctx->opt_blocks_per_cu; return RT_OK;
         case RT_OPT_FILTER: *value = ctx->opt_filter; return RT_OK;
         case RT_OPT_RESOLVE: *value = ctx->opt_resolve; return RT_OK;
+        case RT_OPT_REGROUP: *value = ctx->opt_regroup; return RT_OK;
         case RT_OPT_WAVEFRONT_SLOTS: *value = ctx->opt_wf_slots; return RT_OK;
     }
     return RT_ERR_INVALID;

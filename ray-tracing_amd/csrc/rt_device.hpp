@@ -120,7 +120,8 @@ RT_DEV void get_ray(int i, int j, const Camera &cam, Seed &seed, V3 &dir, V3 &or
 // ---- compact scene --------------------------------------------------------
 // Per object, in the object's original index order.
 struct MatDev {
-    V4 albedo;
+    V4 albedo;     // DIELECTRIC (whose attenuation is 1, Lib.metal:184): x, y = ((1 - ri) / (1 + ri))^2 of Lib.metal:178-179
+                   // for ri = 1 / refraction_index (front hit) and ri = refraction_index (back hit)
     V4 emis;       // emission > 0 ? emission_color * emission : (0,0,0,1)   (Shaders.metal:51-54)
     int type;      // LAMBIERTIAN 0 / REFLECTEE 1 / DIELECTRIC 2, anything else absorbs (Lib.metal:203-213)
     float fuzz;
@@ -270,22 +271,64 @@ RT_DEV float pow5(float x) {
     return (float)(p2 * p2 * p);
 }
 
-// Lib.metal:177-181
-RT_DEV float reflectance(float cosine, float refraction_index) {
-    float r0 = (1.0f - refraction_index) / (1.0f + refraction_index);
-    r0 = r0 * r0;
-    return r0 + (1.0f - r0) * pow5(1.0f - cosine);
+// Lib.metal:177-181.  r0sq = ((1 - ri) / (1 + ri))^2 depends on the material and on the side that was hit only; it is
+// worked out when the scene is uploaded, in the same binary32 operations (MatDev::albedo of a dielectric holds it).
+RT_DEV float reflectance(float cosine, float r0sq) {
+    return r0sq + (1.0f - r0sq) * pow5(1.0f - cosine);
 }
 
 // materialScatters (Lib.metal:157-213).  On return true: attenuation, new ray (dir, origin).
 // Lambertian keeps the reference's field order: the scattered ray's DIRECTION is the hit point and its
 // ORIGIN is normal + random unit vector (Lib.metal:164 initialises Ray{direction, origin} positionally).
+//
+// The lanes of a wave hold all three materials at once, and every branch is paid for by the whole wave, so the
+// operations the branches have in common are written once and run for the lanes of every kind that needs them:
+//   one normalisation: of reflect(d, n) for metal (Lib.metal:170-171) and of d for glass (Lib.metal:187);
+//   one first draw from the seed: the x1 of random_unit_vec's first turn for diffuse and metal (Lib.metal:120, the
+//     first use of the seed in both, :158, :171) and the number glass compares its reflectance with (Lib.metal:196;
+//     not drawn when the ray cannot refract: the reference's || does not evaluate its right side then).
+// Every lane still performs exactly the operations of its own branch, in the reference's order.
 RT_DEV bool scatter(const MatDev &m, V3 &dir, V3 &origin, const Hit &hit, V4 &attenuation, Seed &seed) {
-    // Lambertian and metal both draw one random unit vector, and in both it is the first use of the seed in
-    // the branch (Lib.metal:158, 171), so one rejection loop serves the lanes of both kinds.
-    V3 unit = v3(0.0f, 0.0f, 0.0f);
-    if (m.type == 0 || m.type == 1) unit = random_unit_vec(seed);
-    if (m.type == 0) {
+    const bool diffuse = m.type == 0, metal = m.type == 1, glass = m.type == 2;
+    if (!(diffuse || metal || glass)) return false;
+    V3 u = dir;
+    if (metal) u = reflect(dir, hit.normal);
+    if (metal || glass) u = normalize(u);   // metal: normalize(reflected); glass: unit_direction
+    float cos_theta = 0.0f, ri = 0.0f;
+    bool cannot_refract = false;
+    if (glass) {
+        ri = hit.front ? m.inv_ior : m.ior;
+        cos_theta = __builtin_fminf(dot(-u, hit.normal), 1.0f);
+        float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+        cannot_refract = ri * sin_theta > 1.0f;
+    }
+    float first = 0.0f;
+    if (!(glass && cannot_refract)) first = random_double(seed);
+    if (glass) {
+        attenuation = v4(1.0f, 1.0f, 1.0f, 1.0f);
+        V3 direction;
+        if (cannot_refract || reflectance(cos_theta, hit.front ? m.albedo.x : m.albedo.y) > first) {
+            direction = reflect(u, hit.normal);
+        } else {
+            direction = refract(u, hit.normal, ri);
+        }
+        dir = direction;
+        origin = hit.point;
+        return true;
+    }
+    // Lib.metal:117-132, the first turn's first draw already made
+    float x1 = 2.0f * first - 1.0f;
+    float x2 = 2.0f * random_double(seed) - 1.0f;
+    float w = x1 * x1 + x2 * x2;
+    while (w >= 1.0f) {
+        x1 = 2.0f * random_double(seed) - 1.0f;
+        x2 = 2.0f * random_double(seed) - 1.0f;
+        w = x1 * x1 + x2 * x2;
+    }
+    float multiplier = 2.0f * __builtin_sqrtf(1.0f - w);
+    V3 unit = v3(x1 * multiplier, x2 * multiplier, 1.0f - 2.0f * w);
+    attenuation = m.albedo;
+    if (diffuse) {
         V3 scatter_direction = hit.normal + unit;
         const float s = 1e-8f;
         if ((__builtin_fabsf(scatter_direction.x) < s) && (__builtin_fabsf(scatter_direction.y) < s) &&
@@ -293,33 +336,12 @@ RT_DEV bool scatter(const MatDev &m, V3 &dir, V3 &origin, const Hit &hit, V4 &at
             scatter_direction = hit.normal;
         dir = hit.point;
         origin = scatter_direction;
-        attenuation = m.albedo;
-        return true;
-    } else if (m.type == 1) {
-        V3 reflected = reflect(dir, hit.normal);
-        reflected = normalize(reflected) + (m.fuzz * unit);
-        dir = normalize(reflected);
-        origin = hit.point;
-        attenuation = m.albedo;
-        return dot(dir, hit.normal) > 0.0f;
-    } else if (m.type == 2) {
-        attenuation = v4(1.0f, 1.0f, 1.0f, 1.0f);
-        float ri = hit.front ? m.inv_ior : m.ior;
-        V3 unit_dir = normalize(dir);
-        float cos_theta = __builtin_fminf(dot(-unit_dir, hit.normal), 1.0f);
-        float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
-        bool cannot_refract = ri * sin_theta > 1.0f;
-        V3 direction;
-        if (cannot_refract || reflectance(cos_theta, ri) > random_double(seed)) {
-            direction = reflect(unit_dir, hit.normal);
-        } else {
-            direction = refract(unit_dir, hit.normal, ri);
-        }
-        dir = direction;
-        origin = hit.point;
         return true;
     }
-    return false;
+    V3 reflected = u + (m.fuzz * unit);
+    dir = normalize(reflected);
+    origin = hit.point;
+    return dot(dir, hit.normal) > 0.0f;
 }
 
 // write_color (Shaders.metal:71-85) + linear_to_gamma (Lib.metal:144-150).

@@ -79,6 +79,8 @@ struct TraceParams {
     float4 *target;         // kModeProgressive: rgba32Float render target
     int mode;
     int spp_pass;           // kModeProgressive: Uniforms.sampleCount
+    int regroup;            // staged matrix kind: material scatter regrouped over the workgroup (trace_kernel<..., REGROUP>)
+    int regroup_offset;     // ... and where in the dynamic LDS its lists lie (bytes; set by launch_trace)
 };
 
 // Sample range [ray, ray_end) of chunk number `chunk` of a pixel.

@@ -913,6 +913,45 @@ def test_exact_pass_forms_bit_exact(rt, oracle, renderer, name, w, h, spp, depth
         assert np.array_equal(bits(img), bits(want)), mode
 
 
+@pytest.mark.parametrize("name,w,h,spp,depth,chunk", [("cover", 240, 135, 16, 50, 0), ("cover", 320, 180, 40, 50, 8),
+                                                        ("shells_in_cornell", 160, 120, 8, 20, 0)])
+def test_scatter_regrouped_over_the_workgroup_bit_exact(rt, oracle, renderer, name, w, h, spp, depth, chunk):
+    """RT_OPT_REGROUP 2: the material scatter of a path is evaluated by whichever thread of the workgroup its request is
+    sorted to (one material per wave), and the waves of a workgroup take every trip together -- same operations on
+    the same operands, so the oracle's bits; with more items than lanes, with chunked items, and with quads, emission,
+    absorbing and unknown materials in the scene."""
+    strict(renderer, rt, chunk=chunk)
+    if name == "shells_in_cornell":
+        base, nb = rt.scene("cornell")
+        extra = [rt.makeSphere((200.0 + 40.0 * i, 120.0 + 30.0 * (i % 3), 200.0 + 25.0 * i), 45.0,
+                               [rt.SwiftMaterial.metal(0.8, 0.8, 0.9, 0.3), rt.SwiftMaterial.dielectric(1.5),
+                                rt.SwiftMaterial.lambertian(0.3, 0.7, 0.4)][i % 3]) for i in range(60)]
+        odd = rt.makeSphere((278.0, 60.0, 278.0), 50.0, rt.SwiftMaterial.lambertian(0.5, 0.5, 0.5))
+        odd.mat.type = 7   # no such material: absorbs (Lib.metal:203-213)
+        objs_l = [base[i] for i in range(nb)] + extra + [odd]
+        objs, n = rt.object_array(objs_l), len(objs_l)
+        u = rt.config_uniforms("cornell", w, h, spp, depth, n)
+    else:
+        objs, n = rt.scene(name)
+        u = rt.config_uniforms(name, w, h, spp, depth, n)
+    renderer.setupTexture(w, h)
+    want = oracle.image(u, objs, w, h) if chunk == 0 else None
+    renderer.set_option(rt.RT_OPT_FILTER, 3)
+    try:
+        plain = renderer.renderImage(u, objs, n)
+        assert renderer.lastStats().scene_path == 3
+        renderer.set_option(rt.RT_OPT_REGROUP, 2)
+        img = renderer.renderImage(u, objs, n)
+        st = renderer.lastStats()
+        assert st.scene_path == 3 and st.samples == w * h * spp
+    finally:
+        renderer.set_option(rt.RT_OPT_REGROUP, 0)
+        renderer.set_option(rt.RT_OPT_FILTER, 0)
+    assert np.array_equal(bits(img), bits(plain))
+    if want is not None:
+        assert np.array_equal(bits(img), bits(want))
+
+
 def test_lane_by_lane_exact_pass_on_overlapping_spheres(rt, oracle, renderer):
     """Spheres that overlap pairwise without being duplicates (a ray through the circle in which two of them meet gets
     the same distance from both, possibly from numerators a few ulps apart: the lower object index must win,

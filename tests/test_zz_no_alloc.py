@@ -132,7 +132,7 @@ def test_noalloc_entry_point_under_graph_capture(rt):
     hip.hipGraphLaunch.argtypes = [vp, vp]
     hip.hipGraphExecDestroy.argtypes = [vp]
     hip.hipGraphDestroy.argtypes = [vp]
-    hip.hipMemset.argtypes = [vp, C.c_int, C.c_size_t]
+    hip.hipMemsetAsync.argtypes = [vp, C.c_int, C.c_size_t, vp]
     stream = vp()
     assert hip.hipStreamCreate(C.byref(stream)) == 0
     r = rt.MetalRenderer(device=0, stream=stream.value)
@@ -161,7 +161,8 @@ def test_noalloc_entry_point_under_graph_capture(rt):
         assert rc == 0 and graph.value
         assert hip.hipGraphInstantiate(C.byref(gexec), graph, None, None, 0) == 0
         for rep in range(2):
-            assert hip.hipMemset(r.accumPtr(), 0x7F, w * h * 16) == 0   # whatever the last run left must not matter
+            # whatever the last run left must not matter (dirtied on the context's stream: ordered with the graph)
+            assert hip.hipMemsetAsync(r.accumPtr(), 0x7F, w * h * 16, stream) == 0
             r.clearTexture()
             r.synchronize()
             assert hip.hipGraphLaunch(gexec, stream) == 0
