@@ -85,6 +85,13 @@ enum {
                                cannot win are struck first (bounding balls per 32 and 8 consecutive spheres, then a
                                test per sphere) and dense candidate words go lane by lane, four candidates in flight;
                                1 = always pooled; 2 = always struck and lane by lane */
+    RT_OPT_PLANE_SAMPLES = 12, /* rt_render / rt_render_noalloc sum the samples of a work item one after the other into a
+                               partial sum (a "plane" per item) and add the planes in order.  The items that are drawn
+                               last are cut into planes of this many samples instead: once the work counter is exhausted,
+                               lanes without work take whole planes over from the lane of their wave that has the most
+                               left, so the launch does not end on a few lanes finishing 64-sample items.  -1 (default)
+                               = automatic (4 when RT_OPT_CHUNK is automatic and gives items of 8 samples or more, else 0); 0 = never; else a power of two that
+                               divides the item size.  rt_stats reports the resulting schedule of the sums */
     RT_OPT_REGROUP = 11     /* material scatter of the staged matrix kind's batch kernels (results are identical):
                                0 = automatic (default), 1 = every lane scatters its own path, 2 = requests are sorted by
                                material over the workgroup through LDS, so that a wave runs one branch of the material

@@ -97,6 +97,7 @@ struct rt_ctx {
     int opt_filter = 0;
     int opt_resolve = 0;
     int opt_regroup = 0;
+    int opt_plane = -1;
     int opt_wf_slots = 1 << 20;
 
     rt_stats last = {};
@@ -708,6 +709,9 @@ void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
     P.lift = ctx->lift;
     P.nobj = ctx->nobj;
     P.resolve_mode = ctx->opt_resolve;
+    P.sub_shift = 0;
+    P.fine_begin = 0x7FFFFFFF;
+    P.fine_plane0 = 0;
     P.regroup = ctx->opt_regroup == 2 && ctx->opt_kernel != 1 ? 1 : 0;
     P.dense_kernel = ctx->opt_resolve == 2 || (ctx->opt_resolve == 0 && ctx->scene_dense) ? 1 : 0;
     P.width = ctx->width;
@@ -940,6 +944,11 @@ RT_API int rt_set_option(rt_ctx *ctx, int key, int value) {
             if (value < 0 || value > 2) return fail(ctx, RT_ERR_INVALID, "rt: resolve form must be 0, 1 or 2");
             ctx->opt_resolve = value;
             return RT_OK;
+        case RT_OPT_PLANE_SAMPLES:
+            if (value < -1 || value > 64 || (value > 0 && (value & (value - 1)) != 0))
+                return fail(ctx, RT_ERR_INVALID, "rt: samples per plane must be -1, 0 or a power of two up to 64");
+            ctx->opt_plane = value;
+            return RT_OK;
         case RT_OPT_REGROUP:
             if (value < 0 || value > 2) return fail(ctx, RT_ERR_INVALID, "rt: regroup must be 0, 1 or 2");
             ctx->opt_regroup = value;
@@ -964,6 +973,7 @@ RT_API int rt_get_option(const rt_ctx *ctx, int key, int *value) {
         case RT_OPT_FILTER: *value = ctx->opt_filter; return RT_OK;
         case RT_OPT_RESOLVE: *value = ctx->opt_resolve; return RT_OK;
         case RT_OPT_REGROUP: *value = ctx->opt_regroup; return RT_OK;
+        case RT_OPT_PLANE_SAMPLES: *value = ctx->opt_plane; return RT_OK;
         case RT_OPT_WAVEFRONT_SLOTS: *value = ctx->opt_wf_slots; return RT_OK;
     }
     return RT_ERR_INVALID;
@@ -1124,16 +1134,22 @@ static int render_batch(rt_ctx *ctx, const Uniforms *u, const Object *objs, int 
     int chunk = ctx->opt_chunk, small = ctx->opt_tail_chunk, tail = ctx->opt_tail_samples;
     const long long lanes = (long long)ctx->num_cus * 2048;
     const long long pixels = (long long)u->tileWidth * u->tileHeight;
+    const bool automatic = chunk < 0;
     if (chunk < 0) {
-        // Long items leave lanes idle while the last ones finish -- a loss that grows with chunk / (samples per
-        // lane of the GPU); short items pay for drawing the item and for generating its camera rays (one wave-wide
-        // batch, however few rays) -- a loss that grows with 1 / (chunk x cost of tracing a sample), and that cost
-        // with the number of objects.  The minimum of the sum, with the constant fitted to measurements on the
-        // cover scene (32 at 1080p x 125 samples, 22 at 1080p x 64, 8 at 640x360 x 64); at most 64, one batch.
+        // Long items cost little at the end of a launch -- lanes without work take whole planes over from other lanes of
+        // their wave (below) -- but a wave draws 64 items at a time and cannot take anything over from another wave,
+        // so there must be several items per resident lane; short items pay for drawing the item and for generating
+        // its camera rays (one wave-wide batch, however few rays).  Measured on the cover scene (tools/exp_chunk.py):
+        // 0.4 of the samples a lane of a twice-resident grid would get, at most 64 (one batch), is within 4 % of the best
+        // fixed size from 320x180 x 64 to 1920x1080 x 1000.
+        // Where tracing a sample is cheap (few objects) the batch dominates and longer items win even when that
+        // leaves fewer items than lanes, down to one item per resident lane: the second term (three spheres 400x225 x
+        // 100: 1730 Msamples*px/s with items of 8, 3840 with 32, 2570 with 64).
         const double per_lane = (double)nrays * (double)pixels / (double)lanes;
         const double objects = (double)std::max(1, ctx->nsph + ctx->nquad);
-        chunk = (int)std::lround(std::sqrt(1000.0 * per_lane / objects));
+        chunk = (int)std::lround(std::max(0.4 * per_lane, std::min(2.0 * per_lane, std::sqrt(4000.0 * per_lane / objects))));
         chunk = std::max(1, std::min(64, chunk));
+        if (chunk >= 6) chunk = std::min(64, (chunk + 2) & ~3);  // whole planes of 4 samples (below)
     }
     // A tail of short items after the long ones lets the grid drain more evenly, but on the cover scene it costs
     // more in ray generation than it gains (1 to 2 %): off unless asked for.
@@ -1153,20 +1169,39 @@ static int render_batch(rt_ctx *ctx, const Uniforms *u, const Object *objs, int 
     }
     const unsigned long long nitems = (unsigned long long)pixels * nchunks;
     if (nitems > 0xF0000000ull) return fail(ctx, RT_ERR_TOO_LARGE, "rt: too many work items; raise RT_OPT_CHUNK");
+    // The items drawn last -- the last chunks of every pixel: items are handed out chunk by chunk, and when the counter
+    // runs out the grid holds about lanes / pixels chunks' worth of them -- are cut into finer planes, so that lanes
+    // without work can take whole planes over from others (trace_kernel): automatic for items of 16 samples or more,
+    // or as asked.  Every item must be a whole number of planes.
+    int plane = ctx->opt_plane;
+    if (plane < 0) plane = automatic && small == chunk && chunk >= 8 && chunk % 4 == 0 ? 4 : 0;  // (a given item size is summed as given)
+    if (plane > 0 && (small != chunk || chunk % plane != 0 || plane >= chunk)) plane = 0;
+    int coarse = nchunks, nplanes = nchunks, sub_shift = 0;
+    if (plane > 0) {
+        const int fine_layers = (int)std::min<long long>(nchunks, (lanes + pixels - 1) / pixels + 1);
+        coarse = nchunks - fine_layers;
+        nplanes = coarse + (nrays - coarse * chunk + plane - 1) / plane;
+        if (noalloc && (size_t)nplanes * ctx->width * ctx->height * sizeof(float4) > kScratchPlaneBytes) {
+            plane = 0;   // the static scratch holds fewer planes: one per item
+            coarse = nplanes = nchunks;
+        }
+    }
+    if (plane > 0)
+        for (sub_shift = 0; (1 << sub_shift) < plane; ++sub_shift) {}
     float4 *planes;
     if (noalloc) {
-        const size_t need = (size_t)nchunks * ctx->width * ctx->height * sizeof(float4);
+        const size_t need = (size_t)nplanes * ctx->width * ctx->height * sizeof(float4);
         if (need > kScratchPlaneBytes) {
             char msg[256];
             std::snprintf(msg, sizeof msg,
                           "rt_render_noalloc: %d partial-sum planes of %dx%d need %zu bytes, the static scratch holds %zu; "
                           "raise RT_OPT_CHUNK, trace fewer samples per call, or use rt_render",
-                          nchunks, ctx->width, ctx->height, need, kScratchPlaneBytes);
+                          nplanes, ctx->width, ctx->height, need, kScratchPlaneBytes);
             return fail(ctx, RT_ERR_TOO_LARGE, msg);
         }
         planes = (float4 *)(ctx->scratch_dev + kScratchPlaneOffset);
     } else {
-        RT_TRY(grow(ctx, ctx->planes, (size_t)nchunks * ctx->width * ctx->height));
+        RT_TRY(grow(ctx, ctx->planes, (size_t)nplanes * ctx->width * ctx->height));
         planes = ctx->planes.ptr;
     }
 
@@ -1178,6 +1213,11 @@ static int render_batch(rt_ctx *ctx, const Uniforms *u, const Object *objs, int 
     P.chunk = chunk;
     P.nbig = nbig;
     P.chunk_small = small;
+    if (plane > 0) {
+        P.sub_shift = sub_shift;
+        P.fine_begin = ray_begin + coarse * chunk;
+        P.fine_plane0 = coarse;
+    }
     P.nitems = (uint32_t)nitems;
     P.mode = kModeAccum;
     P.planes = planes;
@@ -1185,11 +1225,12 @@ static int render_batch(rt_ctx *ctx, const Uniforms *u, const Object *objs, int 
     P.plane_stride = (unsigned long long)ctx->width * ctx->height;
     RT_TRY(enqueue_trace(ctx, P, noalloc));
     ctx->last.samples = (uint64_t)u->tileWidth * u->tileHeight * (uint64_t)nrays;
+    // the schedule of the sums, as rt_stats reports it: runs of `chunk` samples (planes), added in order
     ctx->last.chunk = chunk;
-    ctx->last.chunk_count = nbig;
-    ctx->last.tail_chunk = small;
+    ctx->last.chunk_count = plane > 0 ? coarse : nbig;
+    ctx->last.tail_chunk = plane > 0 ? plane : small;
     float4 *acc = accum_dev ? (float4 *)accum_dev : ctx->accum.ptr;
-    RT_HIP(launch_fold(acc, planes, nchunks, ctx->width, ctx->height, P.tileX, P.tileY, P.tileW, P.tileH,
+    RT_HIP(launch_fold(acc, planes, nplanes, ctx->width, ctx->height, P.tileX, P.tileY, P.tileW, P.tileH,
                        ctx->stream));
     return RT_OK;
 }

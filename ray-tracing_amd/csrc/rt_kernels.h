@@ -79,6 +79,11 @@ struct TraceParams {
     float4 *target;         // kModeProgressive: rgba32Float render target
     int mode;
     int spp_pass;           // kModeProgressive: Uniforms.sampleCount
+    // kModeAccum: plane of a sample.  Work items before sample index fine_begin have a plane each, numbered like their
+    // chunks; from fine_begin on (the items that are drawn last) a plane holds 2^sub_shift consecutive samples, plane
+    // fine_plane0 + ((sample - fine_begin) >> sub_shift), several per item, so that lanes without work can take whole
+    // planes over from other lanes once the work counter is exhausted.  fine_begin >= ray_end: no such planes.
+    int sub_shift, fine_begin, fine_plane0;
     int regroup;            // staged matrix kind: material scatter regrouped over the workgroup (trace_kernel<..., REGROUP>)
     int regroup_offset;     // ... and where in the dynamic LDS its lists lie (bytes; set by launch_trace)
 };

@@ -205,6 +205,30 @@ def test_item_schedules_sum_in_the_reported_order(rt, oracle, renderer):
     strict(renderer, rt)
 
 
+@pytest.mark.parametrize("w,h,spp,chunk,plane", [(120, 68, 128, 32, 4), (96, 54, 100, 64, 8), (200, 120, 48, 16, 2)])
+def test_planes_taken_over_at_the_end_of_a_launch_bit_exact(rt, oracle, renderer, w, h, spp, chunk, plane):
+    """Frames so small that the work counter is exhausted almost at once: most of the launch is lanes without work taking
+    planes over from the lanes of their wave that have samples left (RT_OPT_PLANE_SAMPLES).  Whole image against the
+    oracle: every reported range summed sample by sample, the range sums added in order."""
+    strict(renderer, rt, chunk=chunk)
+    renderer.set_option(rt.RT_OPT_PLANE_SAMPLES, plane)
+    objs, n = rt.scene("cover")
+    u = rt.config_uniforms("cover", w, h, spp, 50, n)
+    renderer.setupTexture(w, h)
+    try:
+        img = renderer.renderImage(u, objs, n)
+        st = renderer.lastStats()
+    finally:
+        renderer.set_option(rt.RT_OPT_PLANE_SAMPLES, -1)
+    ranges = st.chunk_ranges(0, spp)
+    assert st.tail_chunk == plane and len(ranges) > spp // chunk   # finer planes at the end
+    assert ranges[0][0] == 0 and ranges[-1][1] == spp and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    sums = np.zeros((h, w, 4), np.float32)
+    for b, e in ranges:
+        sums = sums + oracle.accumulate(u, objs, w, h, b, e)
+    assert np.array_equal(bits(img), bits(oracle.resolve(sums, spp)))
+
+
 def test_sample_split_equals_one_call(rt, renderer):
     """Two calls over [0,s/2) and [s/2,s) into one buffer == one call with chunk s/2 (same add order)."""
     strict(renderer, rt, chunk=8)
