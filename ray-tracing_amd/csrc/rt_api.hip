@@ -403,7 +403,8 @@ bool dense_scene(const std::vector<float4> &sph, int nsph) {  // the first nsph 
 // prune of the group leaves standing.  Stored squared and with the margins the kernel's argument needs: R2out = Rout^2 (1 + 2^-6)
 // rounded up, R2in = Rin^2 (1 - 2^-6) rounded down, and no inner ball (R2in = -1) unless Rin > 0 and the largest radius
 // of the group is at most 64 Rin.  A group with a sphere that is not finite, or without spheres, gets R2out = +inf
-// and R2in = -1: never pruned.  Layout: kBoundVec4 float4 per word: (C, R2out), (R2in, exempt mask bits, 0, 0) of the
+// and R2in = -1: never pruned.  Layout: kBoundVec4 float4 per word: (C, R2out), (R2in, exempt mask bits, 1 if every
+// sphere of the group but the exempt ones has exactly the centre C else 0, 0) of the
 // word, then the same pair for each granule (mask bit of slot p of the word: 0x80000000 >> p).
 void group_bounds(const std::vector<float4> &sph, int i0, int i1, int word0, float4 *out) {
     const float inf = std::numeric_limits<float>::infinity();
@@ -453,6 +454,11 @@ void group_bounds(const std::vector<float4> &sph, int i0, int i1, int word0, flo
     if ((double)fo < r2o) fo = std::nextafterf(fo, inf);
     out[0] = make_float4(c[0], c[1], c[2], fo);
     std::memcpy(&out[1].y, &exempt, sizeof exempt);
+    // every sphere of the group that the balls hold has exactly this centre (concentric shells): the kernels then work
+    // out the ray's numbers about it once for all of them (rt_hit.hpp prune_candidates)
+    bool concentric = true;
+    for (int i = i0; i < i1; ++i) concentric = concentric && ((exempt >> (31 - (i - word0))) & 1u || (sph[(size_t)i].x == c[0] && sph[(size_t)i].y == c[1] && sph[(size_t)i].z == c[2]));
+    out[1].z = concentric ? 1.0f : 0.0f;
     if (rin > 0.0 && rmax <= 64.0 * rin) {
         const double r2i = rin * rin * (1.0 - 0x1p-6);
         float fi = (float)r2i;
@@ -1175,11 +1181,12 @@ static int render_batch(rt_ctx *ctx, const Uniforms *u, const Object *objs, int 
     // or as asked.  Every item must be a whole number of planes.
     int plane = ctx->opt_plane;
     if (plane < 0) plane = automatic && small == chunk && chunk >= 8 && chunk % 4 == 0 ? 4 : 0;  // (a given item size is summed as given)
-    if (plane > 0 && (small != chunk || chunk % plane != 0 || plane >= chunk)) plane = 0;
+    if (plane > 0 && (small % plane != 0 || chunk % plane != 0 || plane >= chunk)) plane = 0;
     int coarse = nchunks, nplanes = nchunks, sub_shift = 0;
     if (plane > 0) {
         const int fine_layers = (int)std::min<long long>(nchunks, (lanes + pixels - 1) / pixels + 1);
-        coarse = nchunks - fine_layers;
+        // (with shorter items at the end: those and the last layer of long ones)
+        coarse = small == chunk ? nchunks - fine_layers : std::max(0, nbig - 1);
         nplanes = coarse + (nrays - coarse * chunk + plane - 1) / plane;
         if (noalloc && (size_t)nplanes * ctx->width * ctx->height * sizeof(float4) > kScratchPlaneBytes) {
             plane = 0;   // the static scratch holds fewer planes: one per item

@@ -64,6 +64,7 @@ struct Fetch<kFetchLds> {  // both arrays staged once per workgroup in LDS, read
     }
     RT_DEV void settle(Rec4 &) const {}
     RT_DEV f4v load1(int k) const { return pg[k]; }
+    RT_DEV float radius(int k) const { return ((const float *)(pg + k))[3]; }
     RT_DEV int object_of(const TraceParams &P, int slot) const { return P.sph_obj[slot]; }
     RT_DEV MatDev material(const TraceParams &P, int obj) const { return P.mats[obj]; }
 };
@@ -90,6 +91,7 @@ struct Fetch<kFetchScalar> {  // scalar cache: uniform address -> s_load_dwordx1
         asm volatile("" : "+s"(r.r0), "+s"(r.r1), "+s"(r.r2), "+s"(r.r3)::"memory");
     }
     RT_DEV f4v load1(int k) const { return strict[k]; }
+    RT_DEV float radius(int k) const { return ((const float *)(strict + k))[3]; }
     RT_DEV int object_of(const TraceParams &P, int slot) const { return P.sph_obj[slot]; }
     RT_DEV MatDev material(const TraceParams &P, int obj) const { return P.mats[obj]; }
 };
@@ -135,6 +137,7 @@ struct Fetch<kFetchStream> {
     }
     RT_DEV void settle(Rec4 &) const {}
     RT_DEV f4v load1(int k) const { return gg[k]; }
+    RT_DEV float radius(int k) const { return ((const float *)(gg + k))[3]; }
     RT_DEV int object_of(const TraceParams &P, int slot) const { return P.sph_obj[slot]; }
     RT_DEV MatDev material(const TraceParams &P, int obj) const { return P.mats[obj]; }
 };
@@ -175,6 +178,7 @@ struct Fetch<kFetchMatrix> {  // strict records and lifted A operands staged in 
     }
     RT_DEV void settle(Rec4 &) const {}
     RT_DEV f4v load1(int k) const { return pg[k]; }
+    RT_DEV float radius(int k) const { return ((const float *)(pg + k))[3]; }
 };
 
 template <>
@@ -760,11 +764,38 @@ RT_DEV bool cannot_win(f4v rec, const PruneRay &y) {
     return no_root_up_to_t(prune_about(rec.x, rec.y, rec.z, y), __builtin_fmaf(-0x1p-10f, r2, r2), __builtin_fmaf(0x1p-10f, r2, r2), 0x1p-15f,
                            0x1p-15f, y);
 }
+// The same test for spheres about one centre (a word of concentric shells): with the ray's numbers q about that centre
+// the comparisons of no_root_up_to_t depend on the sphere through its radius alone, so they are folded into two
+// thresholds per word -- cannot_win(sphere) = r2in > above_in || r2out < below_out, the very comparisons of cannot_win
+// on the very same values, regrouped (max / min of the left-hand sides; a comparison that a flag switches off gets an
+// infinite threshold).
+struct PruneRadii { float above_in, below_out; };
+// no_root_up_to_t(q, r2in, r2out, m_in, m_out, y) == (r2in > above_in) | (r2out < below_out).  A NaN on the left of one of
+// its comparisons makes that comparison fail there; here it makes the threshold infinite, which does the same.
+RT_DEV PruneRadii prune_radii(const PruneAbout &q, const PruneRay &y, float m_in, float m_out) {
+    const float Mi = __builtin_fmaf(m_in, q.X, y.k1), Mo = __builtin_fmaf(m_out, q.X, y.k1);
+    const float inf = __builtin_inff();
+    PruneRadii t;
+    // neg: so + Mi < r2in and sp + Mi < r2in, counted only with a bound
+    const float i0 = q.so + Mi, i1 = q.sp + Mi;
+    t.above_in = (y.has_t & (i0 == i0) & (i1 == i1)) ? __builtin_fmaxf(i0, i1) : inf;
+    // pos0 and behind: so - Mo > r2out;  pos0 and post and ahead (with a bound): so - Mo > r2out and sp - Mo > r2out
+    const float t0 = q.so - Mo, t1 = q.sp - Mo;
+    const float a = (q.behind & (t0 == t0)) ? t0 : -inf;
+    const float b = (y.has_t & q.ahead & (t0 == t0) & (t1 == t1)) ? __builtin_fminf(t0, t1) : -inf;
+    t.below_out = __builtin_fmaxf(a, b);
+    return t;
+}
+RT_DEV bool struck_by(const PruneRadii &t, float r2in, float r2out) { return (r2in > t.above_in) | (r2out < t.below_out); }
+RT_DEV bool cannot_win_radius(const PruneRadii &t, float radius) {  // t = prune_radii(..., 2^-15, 2^-15): cannot_win's margins
+    const float r2 = radius * radius;
+    return struck_by(t, __builtin_fmaf(-0x1p-10f, r2, r2), __builtin_fmaf(0x1p-10f, r2, r2));
+}
 constexpr float kBallMarginIn = 0x1p-15f, kBallMarginOut = 0x1p-8f;
 // Strikes the words whose 32 spheres cannot win as a whole (wave-uniform loop over the words that are non-empty in
 // some lane; the balls come through scalar loads, and a word about the same centre as the one before reuses the
-// ray's numbers about it).  Slots the word's balls leave out (exempt) stay unless the single-sphere test strikes
-// them.  Returns the lane's remaining non-empty words.
+// ray's numbers about it).  Slots the word's balls leave out (exempt) get the single-sphere test, whether the word
+// goes or not.  Returns the lane's remaining non-empty words.
 template <typename F>
 RT_DEV uint32_t cull_words(const F &f, const float4 *word_bounds, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, const PruneRay &y) {
     const const_f4_ptr balls = (const_f4_ptr)(uintptr_t)word_bounds + kBoundVec4 * (slot0 >> 5);
@@ -773,30 +804,30 @@ RT_DEV uint32_t cull_words(const F &f, const float4 *word_bounds, uint32_t *wave
     for (int off = 32; off > 0; off >>= 1) any |= (uint32_t)__shfl_xor((int)any, off, 64);
     any = (uint32_t)__builtin_amdgcn_readfirstlane((int)any);
     float pcx = __builtin_nanf(""), pcy = pcx, pcz = pcx;  // the centre q is about (none yet)
-    PruneAbout q = {};
+    PruneRadii q = {};
     while (any) {
         const int w = __builtin_ctz(any);
         any &= any - 1;
         const f4v outer = balls[kBoundVec4 * w], inner = balls[kBoundVec4 * w + 1];
         const uint32_t exempt = __float_as_uint(inner.y);  // wave-uniform
         if (!(outer.x == pcx && outer.y == pcy && outer.z == pcz)) {
-            q = prune_about(outer.x, outer.y, outer.z, y);
+            q = prune_radii(prune_about(outer.x, outer.y, outer.z, y), y, kBallMarginIn, kBallMarginOut);
             pcx = outer.x; pcy = outer.y; pcz = outer.z;
         }
-        if (no_root_up_to_t(q, inner.x, outer.w, kBallMarginIn, kBallMarginOut, y) && ((nz >> w) & 1u)) {
-            uint32_t m = 0;
-            if (exempt) {
-                // the spheres the balls leave out get the single-sphere test here (same slot for every lane), so
-                // that a lane does not keep a word for the sake of one sphere it could strike
-                uint32_t keep = exempt;
-                for (uint32_t e = exempt; e; e &= e - 1u) {
-                    const int p = 31 - __builtin_ctz(e);  // position in the word
-                    if (cannot_win(f.load1(slot0 + 32 * w + p), y)) keep &= ~(0x80000000u >> p);
-                }
-                m = wave_masks[w * 64 + lane] & keep;
-                wave_masks[w * 64 + lane] = m;
-            }
-            if (m == 0u) nz &= ~(1u << w);
+        // the spheres the balls leave out get the single-sphere test here, for every lane at once (same slot for every
+        // lane): a lane does not keep a word for the sake of one sphere it could strike, and the passes that follow
+        // need not look at these slots again
+        uint32_t keep = exempt;
+        for (uint32_t e = exempt; e; e &= e - 1u) {
+            const int p = 31 - __builtin_ctz(e);  // position in the word
+            if (cannot_win(f.load1(slot0 + 32 * w + p), y)) keep &= ~(0x80000000u >> p);
+        }
+        const bool struck = struck_by(q, inner.x, outer.w);
+        if ((nz >> w) & 1u) {
+            const uint32_t m = wave_masks[w * 64 + lane];
+            const uint32_t m2 = m & (struck ? keep : keep | ~exempt);
+            if (m2 != m) wave_masks[w * 64 + lane] = m2;
+            if (m2 == 0u) nz &= ~(1u << w);
         }
     }
     return nz;
@@ -815,26 +846,32 @@ RT_DEV uint32_t cull_granules(const float4 *word_bounds, uint32_t *wave_masks, u
         const int w = live ? __builtin_ctz(todo) : 0;  // a lane that is through looks at the round's first word again
         todo &= todo - 1;
         const float4 *g4 = balls + kBoundVec4 * w + 2;
-        float4 b[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) b[k] = g4[k];
-        bool same = true;
-#pragma unroll
-        for (int g = 1; g < 4; ++g) same = same & (b[2 * g].x == b[0].x) & (b[2 * g].y == b[0].y) & (b[2 * g].z == b[0].z);
+        // the centres first (a granule's record: (C, R2out), (R2in, exempt bits, 0, 0)): when the four granules of every
+        // lane's word share theirs, the ray's numbers about it are worked out once; the radii are read two granules at a
+        // time, so that the sixteen values of a word are not all in registers at once
+        float4 c0 = g4[0];
+        const float4 c1 = g4[2], c2 = g4[4], c3 = g4[6];
+        const bool same = (c1.x == c0.x) & (c1.y == c0.y) & (c1.z == c0.z) & (c2.x == c0.x) & (c2.y == c0.y) & (c2.z == c0.z) &
+                          (c3.x == c0.x) & (c3.y == c0.y) & (c3.z == c0.z);
         uint32_t kill = 0;
         if (__builtin_amdgcn_ballot_w64(!same) == 0) {
-            const PruneAbout q = prune_about(b[0].x, b[0].y, b[0].z, y);
+            const PruneRadii q = prune_radii(prune_about(c0.x, c0.y, c0.z, y), y, kBallMarginIn, kBallMarginOut);
+            const float w1 = c1.w, w2 = c2.w, w3 = c3.w;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const bool gone = no_root_up_to_t(q, b[2 * g + 1].x, b[2 * g].w, kBallMarginIn, kBallMarginOut, y);
-                kill |= gone ? (0xFF000000u >> (8 * g)) & ~__float_as_uint(b[2 * g + 1].y) : 0u;
+                const float4 in = g4[2 * g + 1];
+                const float r2out = g == 0 ? c0.w : g == 1 ? w1 : g == 2 ? w2 : w3;
+                const bool gone = struck_by(q, in.x, r2out);
+                kill |= gone ? (0xFF000000u >> (8 * g)) & ~__float_as_uint(in.y) : 0u;
             }
         } else {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const PruneAbout q = prune_about(b[2 * g].x, b[2 * g].y, b[2 * g].z, y);
-                const bool gone = no_root_up_to_t(q, b[2 * g + 1].x, b[2 * g].w, kBallMarginIn, kBallMarginOut, y);
-                kill |= gone ? (0xFF000000u >> (8 * g)) & ~__float_as_uint(b[2 * g + 1].y) : 0u;
+                const float4 out = g == 0 ? c0 : g == 1 ? c1 : g == 2 ? c2 : c3;
+                const float4 in = g4[2 * g + 1];
+                const PruneAbout q = prune_about(out.x, out.y, out.z, y);
+                const bool gone = no_root_up_to_t(q, in.x, out.w, kBallMarginIn, kBallMarginOut, y);
+                kill |= gone ? (0xFF000000u >> (8 * g)) & ~__float_as_uint(in.y) : 0u;
             }
         }
         if (live) {
@@ -853,10 +890,17 @@ RT_DEV uint32_t cull_granules(const float4 *word_bounds, uint32_t *wave_masks, u
 // what cannot win and writes the words back; returns the lane's non-empty words and, in left, how many candidates
 // they hold.
 template <typename F>
-RT_DEV uint32_t prune_candidates(const F &f, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, const PruneRay &y, int &left) {
+RT_DEV uint32_t prune_candidates(const F &f, const float4 *word_bounds, uint32_t *wave_masks, uint32_t nz, int slot0, int lane,
+                                 const PruneRay &y, int &left) {
+    const float4 *balls = word_bounds + kBoundVec4 * (slot0 >> 5);
     uint32_t todo = nz, m = 0, word = 0, gone = 0;
     int w = 0;
     left = 0;  // candidates the lane has left
+    // the spheres of the lane's current word, but for those its balls leave out, have one centre (the host says so,
+    // TraceParams::word_bounds), and about is the ray's numbers about it, worked out once per word instead of once per
+    // candidate
+    bool concentric = false;
+    PruneRadii about = {};
     for (;;) {
         if (m == 0) {
             if (gone) {
@@ -870,7 +914,11 @@ RT_DEV uint32_t prune_candidates(const F &f, uint32_t *wave_masks, uint32_t nz, 
             if (todo) {
                 w = __builtin_ctz(todo);
                 todo &= todo - 1;
-                word = m = wave_masks[w * 64 + lane];
+                word = wave_masks[w * 64 + lane];
+                const float4 outer = balls[kBoundVec4 * w], inner = balls[kBoundVec4 * w + 1];
+                m = word & ~__float_as_uint(inner.y);  // the slots the balls leave out have had this test (cull_words)
+                concentric = inner.z != 0.0f;
+                if (concentric) about = prune_radii(prune_about(outer.x, outer.y, outer.z, y), y, 0x1p-15f, 0x1p-15f);
             }
         }
         if (__builtin_amdgcn_ballot_w64(m != 0u) == 0) break;
@@ -882,9 +930,17 @@ RT_DEV uint32_t prune_candidates(const F &f, uint32_t *wave_masks, uint32_t nz, 
         const int p1 = m1 ? __builtin_clz(m1) : p0, p2 = m1 ? 31 - __builtin_ctz(m1) : p3;
         m = live ? m1 & ~((0x80000000u >> p1) | (0x80000000u >> p2)) : 0u;
         const int base = live ? slot0 + w * 32 : slot0 - 31;
-        f4v c0 = f.load1(base + p0), c1 = f.load1(base + p1), c2 = f.load1(base + p2), c3 = f.load1(base + p3);
-        asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
-        const bool g0 = cannot_win(c0, y), g1 = cannot_win(c1, y), g2 = cannot_win(c2, y), g3 = cannot_win(c3, y);
+        bool g0, g1, g2, g3;
+        if (__builtin_amdgcn_ballot_w64(live && !concentric) == 0) {  // every lane that is still at it is in such a word
+            float r0 = f.radius(base + p0), r1 = f.radius(base + p1), r2 = f.radius(base + p2), r3 = f.radius(base + p3);
+            asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+            g0 = cannot_win_radius(about, r0); g1 = cannot_win_radius(about, r1);
+            g2 = cannot_win_radius(about, r2); g3 = cannot_win_radius(about, r3);
+        } else {
+            f4v c0 = f.load1(base + p0), c1 = f.load1(base + p1), c2 = f.load1(base + p2), c3 = f.load1(base + p3);
+            asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+            g0 = cannot_win(c0, y); g1 = cannot_win(c1, y); g2 = cannot_win(c2, y); g3 = cannot_win(c3, y);
+        }
         const uint32_t g = (g0 ? 0x80000000u >> p0 : 0u) | (g1 ? 0x80000000u >> p1 : 0u) | (g2 ? 0x80000000u >> p2 : 0u) | (g3 ? 0x80000000u >> p3 : 0u);
         gone |= live ? g : 0u;
     }
@@ -1025,7 +1081,7 @@ RT_DEV uint32_t resolve_dense_words(const F &f, const float4 *word_bounds, uint3
     for (int off = 32; off > 0; off >>= 1) tally += __shfl_xor(tally, off, 64);
     paid = 3 * (tally & 0xFFFF) <= (tally >> 16);
     int left;
-    nz = prune_candidates(f, wave_masks, nz, slot0, lane, y, left);
+    nz = prune_candidates(f, word_bounds, wave_masks, nz, slot0, lane, y, left);
     if (__builtin_amdgcn_ballot_w64(left > kRestPerLane) == 0) {
         // (3a) few left in every lane: each lane resolves its own, across its words
         nz = resolve_rest_per_lane(f, wave_masks, nz, slot0, lane, o, d, dv, best, prof);
