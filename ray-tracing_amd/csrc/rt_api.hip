@@ -1182,6 +1182,7 @@ static int render_batch(rt_ctx *ctx, const Uniforms *u, const Object *objs, int 
     int plane = ctx->opt_plane;
     if (plane < 0) plane = automatic && small == chunk && chunk >= 8 && chunk % 4 == 0 ? 4 : 0;  // (a given item size is summed as given)
     if (plane > 0 && (small % plane != 0 || chunk % plane != 0 || plane >= chunk)) plane = 0;
+    if (ctx->opt_kernel == 1) plane = 0;  // the wavefront kernels keep one sum per work item
     int coarse = nchunks, nplanes = nchunks, sub_shift = 0;
     if (plane > 0) {
         const int fine_layers = (int)std::min<long long>(nchunks, (lanes + pixels - 1) / pixels + 1);

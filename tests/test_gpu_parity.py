@@ -937,7 +937,7 @@ def test_exact_pass_forms_bit_exact(rt, oracle, renderer, name, w, h, spp, depth
         assert np.array_equal(bits(img), bits(want)), mode
 
 
-@pytest.mark.parametrize("name,w,h,spp,depth,chunk", [("cover", 240, 135, 16, 50, 0), ("cover", 320, 180, 40, 50, 8),
+@pytest.mark.parametrize("name,w,h,spp,depth,chunk", [("cover", 240, 135, 16, 50, 0), ("cover", 320, 180, 40, 50, -1),
                                                         ("shells_in_cornell", 160, 120, 8, 20, 0)])
 def test_scatter_regrouped_over_the_workgroup_bit_exact(rt, oracle, renderer, name, w, h, spp, depth, chunk):
     """RT_OPT_REGROUP 2: the material scatter of a path is evaluated by whichever thread of the workgroup its request is
@@ -1211,6 +1211,29 @@ def test_wavefront_kernels_bit_exact(rt, oracle, renderer, name, w, h, spp, dept
     stats = [0] * 5
     oracle.image(u, objs, w, h, stats=stats)
     assert st.segments == stats[0]
+
+
+def test_wavefront_kernels_with_automatic_items(rt, oracle, renderer):
+    """The wavefront kernels keep one partial sum per work item: with automatic items (which the persistent kernel cuts
+    into finer planes at the end of a launch) the reported schedule must be the one they use."""
+    strict(renderer, rt, chunk=-1)
+    w, h, spp = 320, 180, 40
+    objs, n = rt.scene("cover")
+    u = rt.config_uniforms("cover", w, h, spp, 50, n)
+    renderer.setupTexture(w, h)
+    renderer.set_option(rt.RT_OPT_KERNEL, 1)
+    try:
+        img = renderer.renderImage(u, objs, n)
+        st = renderer.lastStats()
+    finally:
+        renderer.set_option(rt.RT_OPT_KERNEL, 0)
+        strict(renderer, rt)
+    ranges = st.chunk_ranges(0, spp)
+    assert len(ranges) > 1 and ranges[0][0] == 0 and ranges[-1][1] == spp
+    acc = np.zeros((h, w, 4), np.float32)
+    for b, e in ranges:
+        acc = acc + oracle.accumulate(u, objs, w, h, b, e)
+    assert np.array_equal(bits(img), bits(oracle.resolve(acc, spp)))
 
 
 def test_staged_matrix_kind_at_its_largest_scene(rt, renderer):
