@@ -115,7 +115,10 @@ def main():
         raise SystemExit("rank %d has no GPU of its own (%d visible)" % (local_rank, ndev))
     local_rank = local_rank % ndev  # only reachable with --backend gloo: ranks share GPUs for a rehearsal
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # RT_BENCH_FORCE_DIST=1 (under torch.distributed.run --nproc-per-node 1): a one-rank job takes the multi-rank code
+    # path too -- process group, reduce, barrier -- so that the RCCL calls can be exercised on a box with one GPU
+    use_dist = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -165,7 +168,7 @@ def main():
         r.accumClear(accum.data_ptr())
         if end > begin:
             r.render(u, None, 0, begin, end, accum.data_ptr())
-        if world > 1:
+        if use_dist:
             if args.backend == "nccl":
                 dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI; `stream` is current, so it follows the trace
             else:
@@ -177,11 +180,11 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world > 1:
+    if use_dist:
         # build the communicator before anything is timed, whatever --warmup says
         dist.all_reduce(torch.zeros(1, device="cuda" if args.backend == "nccl" else "cpu"))
     for _ in range(args.warmup):
@@ -193,7 +196,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -323,7 +326,7 @@ def main():
             },
             "roofline": roofline,
         }
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

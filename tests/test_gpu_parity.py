@@ -493,6 +493,45 @@ def test_4k_cover_per_rank_share_spot_pixels(rt, oracle, renderer):
     renderer.setupTexture(64, 64)  # give the 4K buffers back
 
 
+def test_bench_rccl_calls_on_one_rank(rt, tmp_path):
+    """The RCCL leg of bench.py -- process group on the nccl backend with the rank's device, the communicator's first
+    all-reduce, the reduce of the accumulation tensor on the script's stream, barrier, MAX of the times, tear-down --
+    executed for real as a one-rank job (RT_BENCH_FORCE_DIST=1), which is all a box with one GPU allows; the reduced
+    sums must equal a plain render of the same frame."""
+    import subprocess
+    import json
+    root = os.path.dirname(HERE)
+    w, h, spp = 320, 180, 16
+    dump = str(tmp_path / "one_rank.npz")
+    port = 29700 + (os.getpid() % 1000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--width", str(w), "--height", str(h), "--spp", str(spp), "--backend", "nccl", "--dump", dump,
+           "--no-cpu-baseline", "--valu-steps", "0"]
+    env = dict(os.environ, OMP_NUM_THREADS="2", RT_BENCH_FORCE_DIST="1")
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=170)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    got = np.load(dump)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    r = rt.MetalRenderer(device=0)
+    try:
+        objs, n = rt.scene("cover")
+        u = rt.config_uniforms("cover", w, h, spp, 50, n)
+        r.setupTexture(w, h)
+        r.setScene(objs, n)
+        r.accumClear()
+        r.render(u, None, 0, 0, spp)
+        r.synchronize()
+        want = np.empty((h, w, 4), np.float32)
+        assert hip.hipMemcpy(want.ctypes.data, r.accumPtr(), want.nbytes, 2) == 0
+    finally:
+        r.close()
+    assert want.any() and np.array_equal(bits(got["accum"]), bits(want))
+
+
 def test_bench_two_ranks_real_path(rt, tmp_path):
     """bench.py's own multi-rank step -- per-rank sample range, trace, reduce to rank 0, resolve -- run as two
     processes (one GPU each when two are visible, else both on GPU 0 with the gloo backend), against the same two
