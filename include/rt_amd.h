@@ -92,6 +92,11 @@ enum {
                                left, so the launch does not end on a few lanes finishing 64-sample items.  -1 (default)
                                = automatic (4 when RT_OPT_CHUNK is automatic and gives items of 8 samples or more, else 0); 0 = never; else a power of two that
                                divides the item size.  rt_stats reports the resulting schedule of the sums */
+    RT_OPT_SHARE = 13,      /* when the lanes of a wave begin to take planes over from each other (RT_OPT_PLANE_SAMPLES):
+                               0 (default) = about one work item per resident lane before the work counter runs out -- a
+                               wave then draws a new item only when none of its lanes has planes left to give, and holds
+                               a few items' worth of samples at the end of the launch instead of half an item per lane;
+                               1 = only once the counter is exhausted.  Results are identical */
     RT_OPT_REGROUP = 11     /* material scatter of the staged matrix kind's batch kernels (results are identical):
                                0 = automatic (default), 1 = every lane scatters its own path, 2 = requests are sorted by
                                material over the workgroup through LDS, so that a wave runs one branch of the material

@@ -98,6 +98,7 @@ struct rt_ctx {
     int opt_resolve = 0;
     int opt_regroup = 0;
     int opt_plane = -1;
+    int opt_share = 0;   // RT_OPT_SHARE
     int opt_wf_slots = 1 << 20;
 
     rt_stats last = {};
@@ -718,6 +719,7 @@ void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
     P.sub_shift = 0;
     P.fine_begin = 0x7FFFFFFF;
     P.fine_plane0 = 0;
+    P.share_begin = 0xFFFFFFFFu;
     P.regroup = ctx->opt_regroup == 2 && ctx->opt_kernel != 1 ? 1 : 0;
     P.dense_kernel = ctx->opt_resolve == 2 || (ctx->opt_resolve == 0 && ctx->scene_dense) ? 1 : 0;
     P.width = ctx->width;
@@ -955,6 +957,10 @@ RT_API int rt_set_option(rt_ctx *ctx, int key, int value) {
                 return fail(ctx, RT_ERR_INVALID, "rt: samples per plane must be -1, 0 or a power of two up to 64");
             ctx->opt_plane = value;
             return RT_OK;
+        case RT_OPT_SHARE:
+            if (value < 0 || value > 1) return fail(ctx, RT_ERR_INVALID, "rt: share must be 0 or 1");
+            ctx->opt_share = value;
+            return RT_OK;
         case RT_OPT_REGROUP:
             if (value < 0 || value > 2) return fail(ctx, RT_ERR_INVALID, "rt: regroup must be 0, 1 or 2");
             ctx->opt_regroup = value;
@@ -980,6 +986,7 @@ RT_API int rt_get_option(const rt_ctx *ctx, int key, int *value) {
         case RT_OPT_RESOLVE: *value = ctx->opt_resolve; return RT_OK;
         case RT_OPT_REGROUP: *value = ctx->opt_regroup; return RT_OK;
         case RT_OPT_PLANE_SAMPLES: *value = ctx->opt_plane; return RT_OK;
+        case RT_OPT_SHARE: *value = ctx->opt_share; return RT_OK;
         case RT_OPT_WAVEFRONT_SLOTS: *value = ctx->opt_wf_slots; return RT_OK;
     }
     return RT_ERR_INVALID;
@@ -1225,6 +1232,12 @@ static int render_batch(rt_ctx *ctx, const Uniforms *u, const Object *objs, int 
         P.sub_shift = sub_shift;
         P.fine_begin = ray_begin + coarse * chunk;
         P.fine_plane0 = coarse;
+        // the lanes of a wave work the last item or so per resident lane off together (never before the fine planes begin)
+        if (ctx->opt_share == 0) {
+            const unsigned long long first_fine = (unsigned long long)coarse * (unsigned long long)pixels;
+            const unsigned long long last = nitems > (unsigned long long)lanes ? nitems - (unsigned long long)lanes : 0;
+            P.share_begin = (uint32_t)std::max(first_fine, last);
+        }
     }
     P.nitems = (uint32_t)nitems;
     P.mode = kModeAccum;

@@ -229,6 +229,44 @@ def test_planes_taken_over_at_the_end_of_a_launch_bit_exact(rt, oracle, renderer
     assert np.array_equal(bits(img), bits(oracle.resolve(sums, spp)))
 
 
+def test_lanes_sharing_items_before_the_counter_runs_out_bit_exact(rt, oracle, renderer):
+    """A frame with many more work items than lanes, so that the waves spend the last item or so per lane sharing their
+    items' planes and drawing new items in between (RT_OPT_SHARE 0): the whole frame equals the one in which planes
+    change lanes only once the counter is exhausted (RT_OPT_SHARE 1), bit for bit, and scattered pixels equal the
+    oracle's sums over the reported ranges."""
+    strict(renderer, rt, chunk=16)
+    w, h, spp = 960, 540, 64
+    objs, n = rt.scene("cover")
+    u = rt.config_uniforms("cover", w, h, spp, 50, n)
+    renderer.setupTexture(w, h)
+    imgs = []
+    try:
+        renderer.set_option(rt.RT_OPT_PLANE_SAMPLES, 4)
+        for share in (0, 1):
+            renderer.set_option(rt.RT_OPT_SHARE, share)
+            imgs.append(renderer.renderImage(u, objs, n))
+            st = renderer.lastStats()
+    finally:
+        renderer.set_option(rt.RT_OPT_SHARE, 0)
+        renderer.set_option(rt.RT_OPT_PLANE_SAMPLES, -1)
+    assert np.array_equal(bits(imgs[0]), bits(imgs[1]))
+    ranges = st.chunk_ranges(0, spp)
+    assert st.tail_chunk == 4 and ranges[-1][1] == spp
+    rng = np.random.RandomState(11)
+    for _ in range(24):
+        x, y = int(rng.randint(0, w)), int(rng.randint(0, h))
+        total = np.zeros(4, np.float32)
+        for b, e in ranges:
+            acc = np.zeros(4, np.float32)
+            for k in range(b, e):
+                c = (C.c_float * 4)()
+                if oracle.lib.rto_sample(C.byref(u), objs, x, y, k, c, None):
+                    acc = acc + np.array(list(c), np.float32)
+            total = total + acc
+        want = oracle.resolve(total.reshape(1, 1, 4), spp)[0, 0]
+        assert np.array_equal(bits(imgs[0][y, x]), bits(want)), (x, y)
+
+
 def test_sample_split_equals_one_call(rt, renderer):
     """Two calls over [0,s/2) and [s/2,s) into one buffer == one call with chunk s/2 (same add order)."""
     strict(renderer, rt, chunk=8)

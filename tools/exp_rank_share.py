@@ -22,18 +22,23 @@ hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
 configs = [(-1, -1), (-1, 0), (64, 8), (64, 0), (32, 8), (64, 4), (64, 16)]
 if len(sys.argv) > 1:
     configs = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
-for spp in (1000, 500, 250, 125):
+for spp in [int(v) for v in os.environ.get('SPP', '1000,500,250,125').split(',')]:
     u = rt.config_uniforms("cover", w, h, 1000, 50, n)
     row = []
-    for chunk, plane in configs:
+    for cfg in configs:
+        chunk, plane = cfg[0], cfg[1]
         r.set_option(rt.RT_OPT_CHUNK, chunk)
         r.set_option(rt.RT_OPT_PLANE_SAMPLES, plane)
+        # optional third and fourth numbers: shorter items at the end of the launch (item size, samples per pixel in them)
+        r.set_option(rt.RT_OPT_TAIL_CHUNK, cfg[2] if len(cfg) > 2 else -1)
+        r.set_option(rt.RT_OPT_TAIL_SAMPLES, cfg[3] if len(cfg) > 3 else -1)
+        r.set_option(rt.RT_OPT_SHARE, cfg[4] if len(cfg) > 4 else 0)  # fifth number: 1 = planes change lanes only once the counter is exhausted
         best, st = 1e30, None
         for rep in range(2):
             r.accumClear(); r.render(u, None, 0, 0, spp); r.synchronize()
             s = r.lastStats()
             if s.kernel_ms < best:
                 best, st = s.kernel_ms, s
-        row.append("%d,%d(%d x%d): %6.1f" % (chunk, plane, st.chunk, st.chunk_count, w * h * spp / best * 1e-3))
+        row.append("%s(%d x%d+%d): %6.1f" % (",".join(str(v) for v in cfg), st.chunk, st.chunk_count, st.tail_chunk, w * h * spp / best * 1e-3))
     print("%4d spp per rank:  " % spp + "   ".join(row), flush=True)
 r.close()
