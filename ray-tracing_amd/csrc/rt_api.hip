@@ -476,6 +476,59 @@ std::vector<float4> word_bounds(const std::vector<float4> &sph, int nsph) {
         group_bounds(sph, i0, std::min(nsph, i0 + 32), i0, rec);
         for (int g = 0; g < 4; ++g) group_bounds(sph, std::min(nsph, i0 + 8 * g), std::min(nsph, i0 + 8 * g + 8), i0, rec + 2 + 2 * g);
     }
+    // Runs: eight or more consecutive slots of finite spheres of positive radius that no word lists as exempt, with
+    // exactly one centre, whose radii never rise (or never fall) from slot to slot -- shells in the order of their
+    // size.  A word all of whose spheres but the exempt ones lie in one run, about the centre its balls are about, gets
+    // the run in its record: third number of the second float4 = 2 (radii fall) or 3 (rise) instead of 1, fourth = the
+    // bits of first slot | (last slot + 1) << 16.  The kernels then find the candidates of such a word that can win by
+    // two binary searches over the run's radii instead of testing them one by one (rt_hit.hpp run_survivors).
+    auto clean = [&](int k) -> bool {
+        const float4 &q = sph[(size_t)k];
+        const uint32_t exempt = [&] { uint32_t e; std::memcpy(&e, &out[(size_t)kBoundVec4 * (size_t)(k / 32) + 1].y, sizeof e); return e; }();
+        return std::isfinite(q.x) && std::isfinite(q.y) && std::isfinite(q.z) && std::isfinite(q.w) && q.w > 0.0f && !((exempt >> (31 - (k & 31))) & 1u);
+    };
+    std::vector<int> run_of((size_t)std::max(nsph, 0), -1);
+    struct Run { int b, e, dir; };
+    std::vector<Run> runs;
+    for (int i = 0; i < nsph && i < 65535;) {
+        if (!clean(i)) {
+            ++i;
+            continue;
+        }
+        int e = i + 1, dir = 0;
+        while (e < nsph && e < 65535 && clean(e) && sph[(size_t)e].x == sph[(size_t)i].x && sph[(size_t)e].y == sph[(size_t)i].y &&
+               sph[(size_t)e].z == sph[(size_t)i].z) {
+            const float a = sph[(size_t)e - 1].w, b = sph[(size_t)e].w;
+            const int step = b < a ? -1 : b > a ? 1 : 0;
+            if (step != 0 && dir != 0 && step != dir) break;
+            if (step != 0) dir = step;
+            ++e;
+        }
+        if (e - i >= 8) {
+            for (int k = i; k < e; ++k) run_of[(size_t)k] = (int)runs.size();
+            runs.push_back({i, e, dir});
+        }
+        i = e;
+    }
+    for (size_t w = 0; w < nwords; ++w) {
+        float4 *rec = out.data() + (size_t)kBoundVec4 * w;
+        if (rec[1].z != 1.0f) continue;  // not about one centre
+        uint32_t exempt;
+        std::memcpy(&exempt, &rec[1].y, sizeof exempt);
+        int run = -2;
+        for (int k = (int)w * 32; k < std::min(nsph, (int)w * 32 + 32); ++k) {
+            if ((exempt >> (31 - (k & 31))) & 1u) continue;
+            if (run == -2) run = run_of[(size_t)k];
+            else if (run != run_of[(size_t)k]) run = -1;
+        }
+        if (run < 0) continue;
+        const Run &r = runs[(size_t)run];
+        const float4 &first = sph[(size_t)r.b];
+        if (!(first.x == rec[0].x && first.y == rec[0].y && first.z == rec[0].z)) continue;
+        rec[1].z = r.dir <= 0 ? 2.0f : 3.0f;
+        const uint32_t bits = (uint32_t)r.b | ((uint32_t)r.e << 16);
+        std::memcpy(&rec[1].w, &bits, sizeof bits);
+    }
     return out;
 }
 

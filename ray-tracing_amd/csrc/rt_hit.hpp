@@ -796,27 +796,67 @@ RT_DEV bool cannot_win_radius(const PruneRadii &t, float radius) {  // t = prune
     return struck_by(t, __builtin_fmaf(-0x1p-10f, r2, r2), __builtin_fmaf(0x1p-10f, r2, r2));
 }
 constexpr float kBallMarginIn = 0x1p-15f, kBallMarginOut = 0x1p-8f;
+// Shells about one centre whose radii fall (or rise) along their slots -- a run, found at scene upload
+// (TraceParams::word_bounds) -- need no walk over candidates at all: cannot_win_radius is monotone in the radius on
+// either side (r2in > above_in holds for the large shells of the run, r2out < below_out for the small ones), so the
+// shells it leaves standing are one range of slots, and two binary searches over the radii find it: [sb, se).
+// Every probe evaluates the very comparison of cannot_win_radius on that slot's radius, so the range is exactly the
+// set of slots of the run that the single-sphere test would leave.
+template <typename F>
+RT_DEV void run_survivors(const F &f, const PruneRadii &t, int rb, int re, bool falling, int &sb, int &se) {
+    const int len = re - rb;
+    // positions j = 0 .. len - 1 in the order of falling radii; first position that is not too large, first that is too small
+    int lo0 = 0, hi0 = len, lo1 = 0, hi1 = len;
+    for (int span = len; span > 0; span >>= 1) {  // enough turns for a range of len + 1 answers (wave-uniform)
+        const int m0 = (lo0 + hi0) >> 1, m1 = (lo1 + hi1) >> 1;
+        const int j0 = min(m0, len - 1), j1 = min(m1, len - 1);
+        float ra = f.radius(falling ? rb + j0 : re - 1 - j0), rc = f.radius(falling ? rb + j1 : re - 1 - j1);
+        asm volatile("" : "+v"(ra), "+v"(rc));
+        const float r2a = ra * ra, r2c = rc * rc;
+        const bool large = __builtin_fmaf(-0x1p-10f, r2a, r2a) > t.above_in;
+        const bool small = __builtin_fmaf(0x1p-10f, r2c, r2c) < t.below_out;
+        if (lo0 < hi0) {
+            if (large) lo0 = m0 + 1; else hi0 = m0;
+        }
+        if (lo1 < hi1) {
+            if (small) hi1 = m1; else lo1 = m1 + 1;
+        }
+    }
+    sb = falling ? rb + lo0 : re - lo1;
+    se = falling ? rb + lo1 : re - lo0;
+}
 // Strikes the words whose 32 spheres cannot win as a whole (wave-uniform loop over the words that are non-empty in
 // some lane; the balls come through scalar loads, and a word about the same centre as the one before reuses the
 // ray's numbers about it).  Slots the word's balls leave out (exempt) get the single-sphere test, whether the word
-// goes or not.  Returns the lane's remaining non-empty words.
+// goes or not.  Words of a run of shells (above) are finished here: every lane keeps the candidates inside its range of
+// the run; runmask returns those words (wave-uniform), run_before / run_after the lane's candidates in them before and
+// after (run_before's upper half: how many of them the lane lost altogether).  Returns the lane's remaining non-empty words.
 template <typename F>
-RT_DEV uint32_t cull_words(const F &f, const float4 *word_bounds, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, const PruneRay &y) {
+RT_DEV uint32_t cull_words(const F &f, const float4 *word_bounds, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, const PruneRay &y,
+                           uint32_t &runmask, int &run_before, int &run_after) {
     const const_f4_ptr balls = (const_f4_ptr)(uintptr_t)word_bounds + kBoundVec4 * (slot0 >> 5);
     uint32_t any = nz;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) any |= (uint32_t)__shfl_xor((int)any, off, 64);
     any = (uint32_t)__builtin_amdgcn_readfirstlane((int)any);
     float pcx = __builtin_nanf(""), pcy = pcx, pcz = pcx;  // the centre q is about (none yet)
-    PruneRadii q = {};
+    PruneAbout about = {};
+    PruneRadii q = {}, q1 = {};   // thresholds with the balls' margins, and with the single-sphere test's (runs)
+    bool q1_valid = false;
+    uint32_t run = 0xFFFFFFFFu;   // the run [sb, se) is the lane's range of
+    int sb = 0, se = 0;
+    runmask = 0;
+    run_before = run_after = 0;
     while (any) {
         const int w = __builtin_ctz(any);
         any &= any - 1;
         const f4v outer = balls[kBoundVec4 * w], inner = balls[kBoundVec4 * w + 1];
         const uint32_t exempt = __float_as_uint(inner.y);  // wave-uniform
         if (!(outer.x == pcx && outer.y == pcy && outer.z == pcz)) {
-            q = prune_radii(prune_about(outer.x, outer.y, outer.z, y), y, kBallMarginIn, kBallMarginOut);
+            about = prune_about(outer.x, outer.y, outer.z, y);
+            q = prune_radii(about, y, kBallMarginIn, kBallMarginOut);
             pcx = outer.x; pcy = outer.y; pcz = outer.z;
+            q1_valid = false;
         }
         // the spheres the balls leave out get the single-sphere test here, for every lane at once (same slot for every
         // lane): a lane does not keep a word for the sake of one sphere it could strike, and the passes that follow
@@ -825,6 +865,31 @@ RT_DEV uint32_t cull_words(const F &f, const float4 *word_bounds, uint32_t *wave
         for (uint32_t e = exempt; e; e &= e - 1u) {
             const int p = 31 - __builtin_ctz(e);  // position in the word
             if (cannot_win(f.load1(slot0 + 32 * w + p), y)) keep &= ~(0x80000000u >> p);
+        }
+        if (inner.z >= 2.0f) {  // (wave-uniform) every slot of the word but the exempt ones belongs to one run
+            const uint32_t r = __float_as_uint(inner.w);
+            if (!q1_valid) {
+                q1 = prune_radii(about, y, 0x1p-15f, 0x1p-15f);
+                q1_valid = true;
+                run = 0xFFFFFFFFu;
+            }
+            if (r != run) {
+                run = r;
+                run_survivors(f, q1, (int)(r & 0xFFFFu), (int)(r >> 16), inner.z == 2.0f, sb, se);
+            }
+            runmask |= 1u << w;
+            if ((nz >> w) & 1u) {
+                const uint32_t m = wave_masks[w * 64 + lane];
+                const int base = slot0 + 32 * w;
+                const int lo = max(sb - base, 0), hi = min(se - base, 32);
+                const uint32_t range = hi > lo ? (0xFFFFFFFFu >> lo) & (0xFFFFFFFFu << (32 - hi)) : 0u;
+                const uint32_t m2 = m & (keep | (range & ~exempt));
+                run_before += __builtin_popcount(m) + (m2 == 0u ? 1 << 16 : 0);  // (upper half: words of runs that went altogether)
+                run_after += __builtin_popcount(m2);
+                if (m2 != m) wave_masks[w * 64 + lane] = m2;
+                if (m2 == 0u) nz &= ~(1u << w);
+            }
+            continue;
         }
         const bool struck = struck_by(q, inner.x, outer.w);
         if ((nz >> w) & 1u) {
@@ -1076,16 +1141,23 @@ RT_DEV uint32_t resolve_dense_words(const F &f, const float4 *word_bounds, uint3
     // (2) ... and did the balls strike two thirds of the candidates of the lanes that came with three or more words?
     // (a word struck as a whole is taken for kDenseWordBits candidates; before in the upper half, after in the lower)
     const int words0 = __builtin_popcount(nz);
-    nz = cull_words(f, word_bounds, wave_masks, nz, slot0, lane, y);
+    uint32_t runmask;
+    int run_before, run_after;
+    nz = cull_words(f, word_bounds, wave_masks, nz, slot0, lane, y, runmask, run_before, run_after);
     int before, after;
-    const int struck = words0 - __builtin_popcount(nz);
-    nz = cull_granules(word_bounds, wave_masks, nz, slot0, lane, y, before, after);
-    int tally = words0 >= 3 ? ((before + kDenseWordBits * struck) << 16) | after : 0;
+    // (the words of runs count with their candidates as they were and as they are, not as words struck)
+    const int struck = words0 - __builtin_popcount(nz) - (run_before >> 16);
+    run_before &= 0xFFFF;
+    const uint32_t nz_run = nz & runmask;   // finished: the passes below leave these words alone
+    nz = cull_granules(word_bounds, wave_masks, nz & ~runmask, slot0, lane, y, before, after);
+    int tally = words0 >= 3 ? ((before + run_before + kDenseWordBits * struck) << 16) | (after + run_after) : 0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tally += __shfl_xor(tally, off, 64);
     paid = 3 * (tally & 0xFFFF) <= (tally >> 16);
     int left;
     nz = prune_candidates(f, word_bounds, wave_masks, nz, slot0, lane, y, left);
+    nz |= nz_run;
+    left += run_after;
     if (__builtin_amdgcn_ballot_w64(left > kRestPerLane) == 0) {
         // (3a) few left in every lane: each lane resolves its own, across its words
         nz = resolve_rest_per_lane(f, wave_masks, nz, slot0, lane, o, d, dv, best, prof);
