@@ -63,6 +63,7 @@ struct rt_ctx {
     DevBuf<float4> sph, sphc;
     DevBuf<_Float16> sphm;  // matrix-core filter: lifted A operands (rt_lift.hpp)
     DevBuf<float4> tiles, tile_frames;  // tiled matrix-core kind (TraceParams::tiles)
+    DevBuf<float4> round_runs;          // the run of shells of every resolve round (TraceParams::round_runs)
     DevBuf<float4> word_bounds;         // balls around and inside every 32 sphere slots (TraceParams::word_bounds)
     DevBuf<int> tile_obj;
     int ntiles = 0;
@@ -532,6 +533,42 @@ std::vector<float4> word_bounds(const std::vector<float4> &sph, int nsph) {
     return out;
 }
 
+// Per resolve round of 512 slots (16 words): the run its words belong to, if all its words of runs belong to one
+// (TraceParams::round_runs).
+std::vector<float4> round_runs(const std::vector<float4> &balls) {
+    const size_t nwords = balls.size() / (size_t)kBoundVec4, nrounds = (nwords + 15) / 16;
+    std::vector<float4> out(2 * std::max<size_t>(nrounds, 1), make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    for (size_t r = 0; r < nrounds; ++r) {
+        uint32_t words = 0, with_exempt = 0, bits = 0;
+        float kind = 0.0f;
+        const float4 *first = nullptr;
+        bool one = true;
+        for (size_t w = 16 * r; w < std::min(nwords, 16 * r + 16); ++w) {
+            const float4 *rec = balls.data() + (size_t)kBoundVec4 * w;
+            uint32_t exempt, b;
+            std::memcpy(&exempt, &rec[1].y, sizeof exempt);
+            std::memcpy(&b, &rec[1].w, sizeof b);
+            if (exempt) with_exempt |= 1u << (w - 16 * r);
+            if (rec[1].z < 2.0f) continue;
+            if (!first) {
+                first = rec;
+                bits = b;
+                kind = rec[1].z;
+            } else if (b != bits || rec[1].z != kind) {
+                one = false;
+            }
+            words |= 1u << (w - 16 * r);
+        }
+        if (!first || !one) continue;
+        const uint32_t masks = words | (with_exempt << 16);
+        out[2 * r] = make_float4(first[0].x, first[0].y, first[0].z, 0.0f);
+        std::memcpy(&out[2 * r].w, &bits, sizeof bits);
+        out[2 * r + 1] = make_float4(0.0f, kind, 0.0f, 0.0f);
+        std::memcpy(&out[2 * r + 1].x, &masks, sizeof masks);
+    }
+    return out;
+}
+
 // Do the bounding balls have something to strike with?  What the kernels for dense scenes gain, they gain from
 // groups of spheres that share an interior (shells within shells: one test strikes every sphere around a ray's
 // segment); among spheres that merely overlap without order (measured on 300 of them: 405 Msamples*px/s pooled, 364-388
@@ -699,6 +736,7 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n, bool *cache_hit = nullp
     RT_TRY(upload(ctx, ctx->tile_frames, tileset.frames));
     const std::vector<float4> balls = word_bounds(sph, nsph);
     RT_TRY(upload(ctx, ctx->word_bounds, balls));
+    RT_TRY(upload(ctx, ctx->round_runs, round_runs(balls)));
     RT_TRY(upload(ctx, ctx->tile_obj, tileset.obj));
     RT_TRY(upload(ctx, ctx->sph_obj, sph_obj));
     RT_TRY(upload(ctx, ctx->quads, quads));
@@ -764,6 +802,7 @@ void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
     P.tiles = ctx->tiles.ptr;
     P.tile_frames = ctx->tile_frames.ptr;
     P.word_bounds = ctx->word_bounds.ptr;
+    P.round_runs = ctx->round_runs.ptr;
     P.tile_obj = ctx->tile_obj.ptr;
     P.ntiles = ctx->ntiles;
     P.lift = ctx->lift;
@@ -953,6 +992,7 @@ RT_API void rt_destroy(rt_ctx *ctx) {
     (void)hipFree(ctx->tiles.ptr);
     (void)hipFree(ctx->tile_frames.ptr);
     (void)hipFree(ctx->word_bounds.ptr);
+    (void)hipFree(ctx->round_runs.ptr);
     (void)hipFree(ctx->tile_obj.ptr);
     (void)hipFree(ctx->sph_obj.ptr);
     (void)hipFree(ctx->quads.ptr);

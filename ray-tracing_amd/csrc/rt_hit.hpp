@@ -18,6 +18,10 @@ constexpr int kRoundWords = 16;   // candidate words per resolve round (512 sphe
 constexpr int kListOffset = kRoundWords * 64;        // after a wave's candidate words: 64 words of candidate list ...
 constexpr int kBestOffset = kListOffset + 64;        // ... and 64 x 64 bits of (distance, slot) minima (resolve_balanced)
 constexpr int kMaskWordsPerWave = kBestOffset + 128; // LDS words per wave
+#ifndef RT_REST_POOLED
+#define RT_REST_POOLED 64
+#endif
+constexpr int kRestPooled = RT_REST_POOLED;  // dense rounds: candidates in the whole wave after the prune up to which the pooled form resolves them
 constexpr int kRestPerLane = 12;   // dense rounds: candidates per lane after the prune up to which every lane resolves its own
 constexpr int kDenseWordBits = 8;  // candidates in a word of 32 spheres from which the word counts as dense (closest_sphere)
 
@@ -832,8 +836,8 @@ RT_DEV void run_survivors(const F &f, const PruneRadii &t, int rb, int re, bool 
 // the run; runmask returns those words (wave-uniform), run_before / run_after the lane's candidates in them before and
 // after (run_before's upper half: how many of them the lane lost altogether).  Returns the lane's remaining non-empty words.
 template <typename F>
-RT_DEV uint32_t cull_words(const F &f, const float4 *word_bounds, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, const PruneRay &y,
-                           uint32_t &runmask, int &run_before, int &run_after) {
+RT_DEV uint32_t cull_words(const F &f, const float4 *word_bounds, const float4 *round_runs, uint32_t *wave_masks, uint32_t nz, int slot0, int lane,
+                           const PruneRay &y, uint32_t &runmask, int &run_before, int &run_after) {
     const const_f4_ptr balls = (const_f4_ptr)(uintptr_t)word_bounds + kBoundVec4 * (slot0 >> 5);
     uint32_t any = nz;
 #pragma unroll
@@ -847,6 +851,49 @@ RT_DEV uint32_t cull_words(const F &f, const float4 *word_bounds, uint32_t *wave
     int sb = 0, se = 0;
     runmask = 0;
     run_before = run_after = 0;
+    // The round's run, when its words of runs all belong to one (TraceParams::round_runs: the usual case, and the record
+    // then saves the loop below its turn per word): the lane's range of the run is found first, its words without exempt
+    // slots that the range does not reach go without being read, and the one or two it reaches keep what lies inside.
+    {
+        const const_f4_ptr rr = (const_f4_ptr)(uintptr_t)round_runs + 2 * (slot0 / (32 * kRoundWords));
+        const f4v ra = rr[0], rb = rr[1];
+        const uint32_t rw = __float_as_uint(rb.x);
+        const uint32_t fast = (rw & 0xFFFFu) & ~(rw >> 16) & any;  // (wave-uniform)
+        if (fast) {
+            about = prune_about(ra.x, ra.y, ra.z, y);
+            q = prune_radii(about, y, kBallMarginIn, kBallMarginOut);
+            q1 = prune_radii(about, y, 0x1p-15f, 0x1p-15f);
+            pcx = ra.x; pcy = ra.y; pcz = ra.z;
+            q1_valid = true;
+            run = __float_as_uint(ra.w);
+            run_survivors(f, q1, (int)(run & 0xFFFFu), (int)(run >> 16), rb.y == 2.0f, sb, se);
+            runmask = fast;
+            any &= ~fast;
+            const int lo_w = max((sb - slot0) >> 5, 0), hi_w = min((se - 1 - slot0) >> 5, kRoundWords - 1);
+            const uint32_t reach = se > sb && hi_w >= lo_w ? ((2u << hi_w) - 1u) & ~((1u << lo_w) - 1u) : 0u;
+            const uint32_t mine = nz & fast;
+            // (a word that goes unread counts like a word the balls strike: kDenseWordBits candidates; see run_before below)
+            const int unread = __builtin_popcount(mine & ~reach);
+            run_before = unread * ((1 << 16) + kDenseWordBits);
+            nz &= ~(mine & ~reach);
+            uint32_t todo = mine & reach;
+            while (__builtin_amdgcn_ballot_w64(todo != 0u)) {
+                const bool live = todo != 0u;
+                const int w = live ? __builtin_ctz(todo) : 0;
+                todo &= todo - 1;
+                const uint32_t m = wave_masks[w * 64 + lane];
+                const int base = slot0 + 32 * w;
+                const int lo = max(sb - base, 0), hi = min(se - base, 32);
+                const uint32_t m2 = hi > lo ? m & (0xFFFFFFFFu >> lo) & (0xFFFFFFFFu << (32 - hi)) : 0u;
+                if (live) {
+                    run_before += __builtin_popcount(m) + (m2 == 0u ? 1 << 16 : 0);
+                    run_after += __builtin_popcount(m2);
+                    if (m2 != m) wave_masks[w * 64 + lane] = m2;
+                    if (m2 == 0u) nz &= ~(1u << w);
+                }
+            }
+        }
+    }
     while (any) {
         const int w = __builtin_ctz(any);
         any &= any - 1;
@@ -1075,7 +1122,7 @@ RT_DEV uint32_t resolve_rest_per_lane(const F &f, const uint32_t *wave_masks, ui
 // paid: the balls struck two thirds of the candidates of the lanes that came with three or more words (the caller's
 // cue to come back).
 template <typename F, bool PROF>
-RT_DEV uint32_t resolve_dense_words(const F &f, const float4 *word_bounds, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, V3 o,
+RT_DEV uint32_t resolve_dense_words(const F &f, const float4 *word_bounds, const float4 *round_runs, uint32_t *wave_masks, uint32_t nz, int slot0, int lane, V3 o,
                                     V3 d, const RootDiv &dv, bool all, int hint, bool &paid, Prof<PROF> &prof) {
     // the lane's closest (distance, slot) so far lives in LDS beside the pooled form's minima (closest_sphere); it is
     // held in registers only here, so that the sphere filter does not carry it
@@ -1136,6 +1183,28 @@ RT_DEV uint32_t resolve_dense_words(const F &f, const float4 *word_bounds, uint3
                 lane_retry(best, r3, (uint32_t)s3, dv, nprune);
             }
         }
+        // these candidates are done with: out of the words, so that the passes below neither test nor resolve them again
+        if (on) {
+            uint32_t clr_b = 0, clr_a = 0;
+            if (k[0] >= 0) clr_b |= 0x80000000u >> ((k[0] - slot0) & 31);
+            if (k[1] >= 0) clr_b |= 0x80000000u >> ((k[1] - slot0) & 31);
+            if (k[2] >= 0) clr_a |= 0x80000000u >> ((k[2] - slot0) & 31);
+            if (k[3] >= 0) clr_a |= 0x80000000u >> ((k[3] - slot0) & 31);
+            if (wa == wb) {
+                clr_b |= clr_a;
+                clr_a = 0;
+            }
+            if (clr_b) {
+                const uint32_t m = wave_masks[wb * 64 + lane] & ~clr_b;
+                wave_masks[wb * 64 + lane] = m;
+                if (m == 0u) nz &= ~(1u << wb);
+            }
+            if (clr_a) {
+                const uint32_t m = wave_masks[wa * 64 + lane] & ~clr_a;
+                wave_masks[wa * 64 + lane] = m;
+                if (m == 0u) nz &= ~(1u << wa);
+            }
+        }
     }
     const PruneRay y = make_prune_ray(o, d, dv.a, best.slot != 0xFFFFFFFFu, best.t);
     // (2) ... and did the balls strike two thirds of the candidates of the lanes that came with three or more words?
@@ -1143,7 +1212,7 @@ RT_DEV uint32_t resolve_dense_words(const F &f, const float4 *word_bounds, uint3
     const int words0 = __builtin_popcount(nz);
     uint32_t runmask;
     int run_before, run_after;
-    nz = cull_words(f, word_bounds, wave_masks, nz, slot0, lane, y, runmask, run_before, run_after);
+    nz = cull_words(f, word_bounds, round_runs, wave_masks, nz, slot0, lane, y, runmask, run_before, run_after);
     int before, after;
     // (the words of runs count with their candidates as they were and as they are, not as words struck)
     const int struck = words0 - __builtin_popcount(nz) - (run_before >> 16);
@@ -1158,7 +1227,14 @@ RT_DEV uint32_t resolve_dense_words(const F &f, const float4 *word_bounds, uint3
     nz = prune_candidates(f, word_bounds, wave_masks, nz, slot0, lane, y, left);
     nz |= nz_run;
     left += run_after;
-    if (__builtin_amdgcn_ballot_w64(left > kRestPerLane) == 0) {
+    // (3) A handful left in the whole wave: the pooled form resolves them in a flush or two, every lane one candidate
+    // (a turn of the per-lane form costs four candidates' arithmetic in every lane, however few have any).
+    int total = left;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
+    if (total <= kRestPooled) {
+        // nothing here: the caller's resolve_balanced takes what the words still hold
+    } else if (__builtin_amdgcn_ballot_w64(left > kRestPerLane) == 0) {
         // (3a) few left in every lane: each lane resolves its own, across its words
         nz = resolve_rest_per_lane(f, wave_masks, nz, slot0, lane, o, d, dv, best, prof);
     } else {
@@ -1264,7 +1340,7 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
                 const bool qualifies = __builtin_amdgcn_ballot_w64(__builtin_popcount(nz) >= 4) != 0;
                 if (P.resolve_mode == 2 || (qualifies && (work.unpaid < 4u || (work.trips & 15u) == 0u))) {
                     bool paid;
-                    nz = resolve_dense_words(f, P.word_bounds, wave_masks, nz, 4 * g0, lane, o, d, dv, P.resolve_mode == 2, work.last_slot, paid, prof);
+                    nz = resolve_dense_words(f, P.word_bounds, P.round_runs, wave_masks, nz, 4 * g0, lane, o, d, dv, P.resolve_mode == 2, work.last_slot, paid, prof);
                     if (qualifies) work.unpaid = paid ? 0u : min(work.unpaid + 1u, 4u);
                 }
             }

@@ -53,6 +53,9 @@ struct TraceParams {
                             // this is set: scenes whose rays cross many spheres, or resolve_mode 2)
     const float4 *word_bounds;  // kBoundVec4 float4 per word of 32 sphere slots: balls around and inside the word's spheres and
                                 // around and inside each of its four granules of 8 (rt_api.hip group_bounds)
+    const float4 *round_runs;   // two float4 per resolve round of 512 slots: (centre, bits of first slot | end slot << 16 of the run)
+                                // and (bits of the round's words of that run | its words with exempt slots << 16, 2 if the radii
+                                // fall along the slots else 3, 0, 0); no words when the round's words of runs are not all of one run
     float4 *rayq;           // per-wave queues of generated camera rays: grid lanes x kQueueRays x 2 float4
     int maxDepth;           // Uniforms.maxRayDepth
     V4 sky;                 // Uniforms.globalIllumation
