@@ -93,10 +93,13 @@ enum {
                                = automatic (4 when RT_OPT_CHUNK is automatic and gives items of 8 samples or more, else 0); 0 = never; else a power of two that
                                divides the item size.  rt_stats reports the resulting schedule of the sums */
     RT_OPT_SHARE = 13,      /* when the lanes of a wave begin to take planes over from each other (RT_OPT_PLANE_SAMPLES):
-                               0 (default) = about one work item per resident lane before the work counter runs out -- a
-                               wave then draws a new item only when none of its lanes has planes left to give, and holds
-                               a few items' worth of samples at the end of the launch instead of half an item per lane;
-                               1 = only once the counter is exhausted.  Results are identical */
+                               1 (default) = once the work counter is exhausted; 0 = from about one work item per resident
+                               lane before that -- a wave then draws a new item only when none of its lanes has planes left
+                               to give, and holds a few items' worth of samples at the end of the launch instead of half an
+                               item per lane; a wave whose lanes finish planes faster than one hand-over per turn can serve
+                               them (short paths) goes back to an item per lane.  Results are identical.  Measured: one
+                               rank's share of the benchmark frame at 8 ranks +0.4 %, nested shells -5 %, Cornell box -2 %,
+                               hence not the default */
     RT_OPT_REGROUP = 11     /* material scatter of the staged matrix kind's batch kernels (results are identical):
                                0 = automatic (default), 1 = every lane scatters its own path, 2 = requests are sorted by
                                material over the workgroup through LDS, so that a wave runs one branch of the material

@@ -99,7 +99,7 @@ struct rt_ctx {
     int opt_resolve = 0;
     int opt_regroup = 0;
     int opt_plane = -1;
-    int opt_share = 0;   // RT_OPT_SHARE
+    int opt_share = 1;   // RT_OPT_SHARE
     int opt_wf_slots = 1 << 20;
 
     rt_stats last = {};

@@ -1336,7 +1336,9 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
         // a round that does not pay costs here, hence the patience).  (A wave with a ray whose a = d.d is out of the
         // range of the shared-reciprocal division stays pooled.)
         if constexpr (DENSE) {
-            if (P.resolve_mode != 1 && !dv.slow) {
+            // (dense_kernel: the stamped instantiation carries this code for every scene, and must not take it where the
+            // kernels it stands in for would not)
+            if (P.dense_kernel != 0 && P.resolve_mode != 1 && !dv.slow) {
                 const bool qualifies = __builtin_amdgcn_ballot_w64(__builtin_popcount(nz) >= 4) != 0;
                 if (P.resolve_mode == 2 || (qualifies && (work.unpaid < 4u || (work.trips & 15u) == 0u))) {
                     bool paid;

@@ -88,9 +88,9 @@ struct TraceParams {
     // planes over from other lanes once the work counter is exhausted.  fine_begin >= ray_end: no such planes.
     int sub_shift, fine_begin, fine_plane0;
     // Work items from number share_begin on (inside the fine planes, about the last item per resident lane) are worked
-    // off by the lanes of a wave together: a lane without work takes the upper half of another lane's untouched planes
-    // before the wave draws a new item, so that a wave holds a few items' worth of samples when the counter runs out
-    // instead of half an item per lane.  0xFFFFFFFF: only once the counter is exhausted.
+    // off by the lanes of a wave together (RT_OPT_SHARE 0): a lane without work takes the upper half of another lane's
+    // untouched planes before the wave draws a new item, so that a wave holds a few items' worth of samples when the
+    // counter runs out instead of half an item per lane.  0xFFFFFFFF (the default): only once the counter is exhausted.
     uint32_t share_begin;
     int regroup;            // staged matrix kind: material scatter regrouped over the workgroup (trace_kernel<..., REGROUP>)
     int regroup_offset;     // ... and where in the dynamic LDS its lists lie (bytes; set by launch_trace)

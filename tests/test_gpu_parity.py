@@ -247,7 +247,7 @@ def test_lanes_sharing_items_before_the_counter_runs_out_bit_exact(rt, oracle, r
             imgs.append(renderer.renderImage(u, objs, n))
             st = renderer.lastStats()
     finally:
-        renderer.set_option(rt.RT_OPT_SHARE, 0)
+        renderer.set_option(rt.RT_OPT_SHARE, 1)
         renderer.set_option(rt.RT_OPT_PLANE_SAMPLES, -1)
     assert np.array_equal(bits(imgs[0]), bits(imgs[1]))
     ranges = st.chunk_ranges(0, spp)

@@ -32,7 +32,7 @@ for spp in [int(v) for v in os.environ.get('SPP', '1000,500,250,125').split(',')
         # optional third and fourth numbers: shorter items at the end of the launch (item size, samples per pixel in them)
         r.set_option(rt.RT_OPT_TAIL_CHUNK, cfg[2] if len(cfg) > 2 else -1)
         r.set_option(rt.RT_OPT_TAIL_SAMPLES, cfg[3] if len(cfg) > 3 else -1)
-        r.set_option(rt.RT_OPT_SHARE, cfg[4] if len(cfg) > 4 else 0)  # fifth number: 1 = planes change lanes only once the counter is exhausted
+        r.set_option(rt.RT_OPT_SHARE, cfg[4] if len(cfg) > 4 else 1)  # fifth number: 0 = planes change lanes before the counter is exhausted too
         best, st = 1e30, None
         for rep in range(2):
             r.accumClear(); r.render(u, None, 0, 0, spp); r.synchronize()
