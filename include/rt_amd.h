@@ -98,7 +98,7 @@ enum {
                                to give, and holds a few items' worth of samples at the end of the launch instead of half an
                                item per lane; a wave whose lanes finish planes faster than one hand-over per turn can serve
                                them (short paths) goes back to an item per lane.  Results are identical.  Measured: one
-                               rank's share of the benchmark frame at 8 ranks +0.4 %, nested shells -5 %, Cornell box -2 %,
+                               rank's share of the benchmark frame at 8 ranks +0.4 %, nested shells +1.3 %, Cornell box -4 %,
                                hence not the default */
     RT_OPT_REGROUP = 11     /* material scatter of the staged matrix kind's batch kernels (results are identical):
                                0 = automatic (default), 1 = every lane scatters its own path, 2 = requests are sorted by
