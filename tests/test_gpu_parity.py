@@ -1137,10 +1137,23 @@ def _dense_scene(rt, kind):
             if k % 41 == 9:
                 objs.append(rt.makeSphere((0.0, 0.0, -1.0), 0.5 * (1.0 - k / 260.0), grey))   # coincides with a shell
         return objs, (0.0, 0.25, 1.0), (0.0, 0.0, -1.0)
+    if kind == "rising_shells":
+        # shells about one centre with radii that rise along the slots, every 30th twice (equal roots: the lower slot
+        # must win), a second set about another centre with falling radii beginning in the middle of a word, the ground
+        # last: runs of both directions, a word that two runs share, an exempt sphere in the last word
+        objs = []
+        for k in range(200):
+            objs.append(rt.makeSphere((0.0, 0.0, -1.0), 0.5 * (k + 1) / 200.0, glass if k % 2 == 0 else air))
+            if k % 30 == 11:
+                objs.append(rt.makeSphere((0.0, 0.0, -1.0), 0.5 * (k + 1) / 200.0, grey))
+        for k in range(120):
+            objs.append(rt.makeSphere((0.9, 0.1, -1.3), 0.3 * (1.0 - k / 120.0), glass if k % 2 == 0 else air))
+        objs.append(rt.makeSphere((0.0, -100.5, -1.0), 100.0, rt.SwiftMaterial.lambertian(0.8, 0.8, 0.0)))
+        return objs, (0.4, 0.25, 1.0), (0.3, 0.0, -1.1)
     raise ValueError(kind)
 
 
-@pytest.mark.parametrize("kind", ["drifting_shells", "clutter", "far_shells", "shells_and_strays"])
+@pytest.mark.parametrize("kind", ["drifting_shells", "clutter", "far_shells", "shells_and_strays", "rising_shells"])
 def test_pruned_exact_pass_on_dense_scenes(rt, oracle, renderer, kind):
     """Kernels for scenes whose rays cross many spheres strike candidates that cannot win before the exact pass (whole
     words and granules by their bounding balls, single spheres by a test with margins).  Their images must have the
@@ -1167,7 +1180,7 @@ def test_pruned_exact_pass_on_dense_scenes(rt, oracle, renderer, kind):
     assert np.array_equal(bits(imgs[1]), bits(oracle.image(u, arr, w, h)))
 
 
-@pytest.mark.parametrize("kind", ["nested_glass", "drifting_shells", "clutter", "far_shells", "shells_and_strays", "cover"])
+@pytest.mark.parametrize("kind", ["nested_glass", "drifting_shells", "clutter", "far_shells", "shells_and_strays", "rising_shells", "cover"])
 def test_prune_strikes_nothing_the_reference_would_take(rt, renderer, kind):
     """rt_selftest_prune on the scene's own spheres and bounding balls: rays from on or next to surfaces, tangent or
     aimed at silhouettes, with bounds equal to other spheres' roots or a few ulps off them, every sphere against the

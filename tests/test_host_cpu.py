@@ -220,6 +220,49 @@ def test_group_bounds_hold_what_the_prune_assumes(rt):
     assert rt.amd_lib().rt_group_bounds(None, -1, None) < 0
 
 
+def test_runs_of_shells_are_marked_where_the_radii_are_in_order(rt):
+    """Words of 32 slots whose spheres (but for the exempt ones) belong to one run -- consecutive slots about exactly one
+    centre with radii that never rise, or never fall -- carry the run in their record: third number of the second float4
+    2 (falling) or 3 (rising) instead of 1, fourth the bits of first slot | end slot << 16.  The kernels find a ray's
+    candidates among such shells by binary search over the radii, so the order must be what the record says."""
+    shells = np.array([[0.0, 0.0, -1.0, 0.5 * (1.0 - k / 400.0)] for k in range(400)], np.float32)
+
+    def runs(sph):
+        b = rt.group_bounds(sph.astype(np.float32))
+        return [(float(b[w, 0, 1, 2]), int(b[w, 0, 1, 3:4].view(np.uint32)[0])) for w in range(len(b))]
+
+    # the nested-shell configuration: ground sphere (exempt) in slot 0, shells with falling radii in slots 1..400
+    got = runs(np.vstack([[[0.0, -100.5, -1.0, 100.0]], shells]))
+    assert all(kind == 2.0 and bits == (1 | (401 << 16)) for kind, bits in got), got
+    # rising radii; two runs that meet inside a word (that word is about one centre but in no single run)
+    got = runs(shells[::-1])
+    assert all(kind == 3.0 and bits == (0 | (400 << 16)) for kind, bits in got)
+    both = np.vstack([shells[:48], shells[:48][::-1]])
+    got = runs(both)
+    # (slot 48 repeats the radius of slot 47, so it still belongs to the falling run)
+    assert got[0] == (2.0, 0 | (49 << 16)) and got[1][0] == 1.0 and got[2] == (3.0, 49 | (96 << 16)), got
+    # a stray sphere among the shells is exempt and splits the run; shells whose centres drift are in no run
+    strays = np.vstack([shells[:40], [[0.3, 0.2, -0.7, 0.05]], shells[40:77]])
+    got = runs(strays)
+    assert got[0] == (2.0, 0 | (40 << 16)) and got[1][0] == 1.0 and got[2] == (2.0, 41 | (78 << 16)), got
+    drifting = np.array([[0.002 * k, 0.0, -1.0, 0.5 - 0.002 * k] for k in range(200)], np.float32)
+    assert all(kind < 2.0 for kind, _ in runs(drifting))
+    # radii out of order, a negative radius, a value that is not a number: no run through them
+    rng = np.random.default_rng(7)
+    assert all(kind < 2.0 for kind, _ in runs(shells[rng.permutation(64)]))
+    bad = shells[:64].copy()
+    bad[20, 3] = -0.3
+    got = runs(bad)
+    assert got[0][0] < 2.0 and got[1] == (2.0, 32 | (64 << 16)) or got[1] == (2.0, 21 | (64 << 16)), got
+    bad = shells[:64].copy()
+    bad[40, 3] = np.nan
+    assert runs(bad)[1][0] < 2.0
+    # equal radii count as in order
+    same = shells[:64].copy()
+    same[:, 3] = 0.25
+    assert all(kind == 2.0 for kind, _ in runs(same))
+
+
 def test_matrix_results_are_read_at_a_safe_distance():
     """MI355X does not interlock a vector read of a matrix instruction's result (tools/mfma_hazard_probe.hip: result
     register r is written 5 + r/2 wait states after issue, and the ROCm 7.2 compiler spaces reads by 11 where the last

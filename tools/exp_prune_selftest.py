@@ -16,7 +16,7 @@ blocks = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 rays = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 r = rt.MetalRenderer(0)
 bad = 0
-for kind in ("nested_glass", "cover", "drifting_shells", "clutter", "far_shells", "shells_and_strays"):
+for kind in ("nested_glass", "cover", "drifting_shells", "clutter", "far_shells", "shells_and_strays", "rising_shells"):
     if kind in ("nested_glass", "cover"):
         arr, n = rt.scene(kind)
     else:
