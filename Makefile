@@ -13,9 +13,15 @@ HIP_HDRS = $(wildcard $(PKG)/csrc/*.h) $(wildcard $(PKG)/csrc/*.hpp) $(wildcard 
 
 all: $(LIBDIR)/librt_amd.so $(LIBDIR)/librt_host.so $(LIBDIR)/rt_render oracle
 
-$(LIBDIR)/librt_amd.so: $(HIP_SRCS) $(HIP_HDRS)
-	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS)
+# one object per source file, each with the extra flags csrc/FLAGS lists for it
+OBJDIR = $(LIBDIR)/obj
+HIP_OBJS = $(patsubst $(PKG)/csrc/%.hip,$(OBJDIR)/%.o,$(HIP_SRCS))
+$(OBJDIR)/%.o: $(PKG)/csrc/%.hip $(HIP_HDRS) $(PKG)/csrc/FLAGS
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(shell sed -n 's/^$*\.hip //p' $(PKG)/csrc/FLAGS) -c -o $@ $<
+
+$(LIBDIR)/librt_amd.so: $(HIP_OBJS)
+	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $(HIP_OBJS)
 
 $(LIBDIR)/librt_host.so: $(PKG)/host/rt_host.c $(PKG)/host/rt_host.h include/rt_abi.h
 	@mkdir -p $(LIBDIR)
@@ -37,7 +43,7 @@ tools/%: tools/%.hip $(HIP_HDRS)
 host: $(LIBDIR)/librt_host.so
 
 clean:
-	rm -f $(LIBDIR)/*.so $(LIBDIR)/rt_render
+	rm -f $(LIBDIR)/*.so $(LIBDIR)/rt_render $(OBJDIR)/*.o
 	$(MAKE) -C oracle clean
 
 .PHONY: tools all oracle host clean

@@ -13,7 +13,7 @@ The ROCm 7.2 compiler keeps every such read 11 wait states behind the matrix ins
 three registers.  The library's own code reads the registers in ascending order, which keeps it safe; this script
 proves that on the compiled ISA so that a compiler or source change that breaks it is caught without a GPU.
 
-    tools/check_mfma_distance.py ray-tracing_amd/csrc/rt_trace.hip [more .hip files]
+    tools/check_mfma_distance.py [ray-tracing_amd/csrc/rt_trace.hip more .hip files]      (default: every file with matrix code)
 
 Exit status 1 and one line per violation if any register of a matrix result is touched too early.  Only the
 fall-through path is followed (a taken branch inside the 12-instruction window is not).
@@ -90,7 +90,12 @@ def check(asm_path):
 
 
 def main(argv):
-    sources = argv[1:] or [os.path.join(ROOT, "ray-tracing_amd", "csrc", f) for f in ("rt_trace.hip", "rt_wavefront.hip")]
+    sources = argv[1:] or [os.path.join(ROOT, "ray-tracing_amd", "csrc", f) for f in ("rt_trace.hip", "rt_trace_dense.hip", "rt_wavefront.hip")]
+    # the extra flags the build gives a source file (csrc/FLAGS: file name, then the flags)
+    extra = {}
+    for line in open(os.path.join(ROOT, "ray-tracing_amd", "csrc", "FLAGS")):
+        if line.strip() and not line.startswith("#"):
+            extra[line.split()[0]] = line.split()[1:]
     bad, count = [], 0
     with tempfile.TemporaryDirectory() as tmp:
         for src in sources:
@@ -98,7 +103,7 @@ def main(argv):
                 asm = src
             else:
                 asm = os.path.join(tmp, os.path.basename(src) + ".s")
-                subprocess.run([HIPCC] + FLAGS + ["-o", asm, src], check=True, stderr=subprocess.DEVNULL)
+                subprocess.run([HIPCC] + FLAGS + extra.get(os.path.basename(src), []) + ["-o", asm, src], check=True, stderr=subprocess.DEVNULL)
             count += sum(1 for _, _, op, _ in instructions(asm) if op.startswith("v_mfma_f32_32x32x16"))
             bad += check(asm)
     for b in bad:

@@ -1,7 +1,9 @@
 #!/bin/bash
 # Per-kernel register, spill and occupancy table of one .hip file (compiler remarks, no GPU needed).
 #   tools/kernel_resources.sh ray-tracing_amd/csrc/rt_trace.hip
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC -c "$1" -o /dev/null -Rpass-analysis=kernel-resource-usage 2>&1 |
+# (with the extra flags ray-tracing_amd/csrc/FLAGS lists for the file, as the Makefile builds it)
+EXTRA=$(sed -n "s/^$(basename "$1") //p" "$(dirname "$0")/../ray-tracing_amd/csrc/FLAGS")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC $EXTRA -c "$1" -o /dev/null -Rpass-analysis=kernel-resource-usage 2>&1 |
   python3 -c '
 import re, sys, subprocess
 rows, cur = [], None
