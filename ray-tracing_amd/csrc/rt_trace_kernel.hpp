@@ -1,6 +1,7 @@
 // rt_trace_kernel.hpp -- the persistent path-tracing kernel (a template over the record fetcher and the forms of its
-// phases), shared by the two translation units that instantiate it: rt_trace.hip (the kernels every scene runs) and
-// rt_trace_dense.hip (the instantiations that carry the pruning exact pass, and the stamped diagnostic ones).  They are
+// phases), shared by the two translation units that instantiate it: rt_trace.hip (the kernels most scenes run) and
+// rt_trace_dense.hip (the instantiations that carry the pruning exact pass, the stamped diagnostic ones, and the
+// vector-filter kinds for scenes of many spheres).  They are
 // compiled with different instruction-scheduling strategies (csrc/FLAGS).
 #pragma once
 
@@ -38,7 +39,9 @@ struct RegroupLds {
     uint16_t idx[1024];   // wave * 64 + lane of the request a thread serves
 };
 
-template <int KIND, bool PROF, bool SINGLE = false, bool DENSE = false, bool REGROUP = false>
+// BUILD: nothing in the kernel depends on it; it keeps apart instantiations that two translation units compile with
+// different flags (same template arguments would make them one symbol, and one of the two builds would be dropped).
+template <int KIND, bool PROF, bool SINGLE = false, bool DENSE = false, bool REGROUP = false, int BUILD = 0>
 __global__ __launch_bounds__(KIND == kFetchMatrix || KIND == kFetchTiled ? 1024 : 256) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void trace_kernel(const TraceParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_words[];
@@ -512,7 +515,12 @@ void trace_kernel(const TraceParams P) {
     }
 }
 
-// The instantiations of rt_trace_dense.hip: DENSE (fetch kinds other than the tiled one) and PROF.  Null when there is none.
+// The instantiations of rt_trace_dense.hip: DENSE (fetch kinds other than the tiled one) and PROF ...
 const void *trace_kernel_dense(int fetch_kind, bool profile, bool single);
+// ... and the plain kernels of the vector-filter kinds for scenes of kManySpheres spheres or more, where the filter loop
+// is most of a trip (the register-minimising schedule of rt_trace.hip costs that loop 11 %, and gains the same kernels
+// 3 to 10 % on scenes of a few objects).  Null when there is none.
+const void *trace_kernel_many(int fetch_kind, bool single);
+constexpr int kManySpheres = 48;
 
 }  // namespace rt
