@@ -251,14 +251,16 @@ def main():
         # HBM traffic of the trace kernel is not measurable from inside this process: it is replayed from the counter
         # run committed under profiles/, and only while that run was taken on this workload and this kernel source.
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "trace_hbm_bytes.json")
-        if world == 1 and os.path.exists(pmc_path):
+        import glob
+        runs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_trace_hbm_bytes.json")))   # the latest round's counter run
+        pmc_path = runs[-1] if runs else ""
+        if world == 1 and pmc_path:
             try:
                 rec = json.load(open(pmc_path))
                 if (rec.get("workload") == "%s %dx%d %dspp" % (args.scene, W, H, spp)
                         and rec.get("kernel_source_id") == ge.kernel_source_id()):
                     traffic = rec.get("bytes_per_launch")
-                    traffic_src = "replayed from profiles/trace_hbm_bytes.json (rocprofv3 --pmc run of this workload, kernel source %s)" % rec.get("kernel_source_id")
+                    traffic_src = "replayed from profiles/%s (rocprofv3 --pmc run of this workload, kernel source %s)" % (os.path.basename(pmc_path), rec.get("kernel_source_id"))
             except Exception:
                 traffic = None
         if matrix:

@@ -51,7 +51,6 @@ line = last_json(os.path.join(src, "bench_line.txt"))
 assert line["config"]["kernel_source_id"] == kid, "the tree changed since the run"
 subprocess.check_call([sys.executable, os.path.join(root, "tools", "summarize_profile.py"), os.path.join(src, "bench"), prefix,
                        "cover 1920x1080 1000spp", kid], stdout=subprocess.DEVNULL)
-shutil.copy(prefix + "_trace_hbm_bytes.json", os.path.join(os.path.dirname(prefix), "trace_hbm_bytes.json"))
 json.dump(line, open(prefix + "_bench_line.json", "w"), indent=1)
 # nested shells and 100 000 spheres
 shutil.copy(os.path.join(src, "nested", "stats", "run_kernel_stats.csv"), prefix + "_nested_kernel_stats.csv")
