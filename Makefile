@@ -33,9 +33,9 @@ $(LIBDIR)/rt_render: $(PKG)/host/rt_cli.c $(PKG)/host/rt_renderer.c $(PKG)/host/
 oracle:
 	$(MAKE) -C oracle
 
-# instruction-rate and matrix-core probes behind the design (profiles/r01_*.txt are their outputs)
+# instruction-rate and matrix-core probes behind the design (their outputs are under profiles/)
 TOOLS = tools/valu_rate tools/mfma_coexec tools/mfma_f16_probe tools/mfma_split_probe tools/op_rate tools/div_probe \
-        tools/filter_probe tools/mfma_hazard_probe
+        tools/filter_probe tools/mfma_hazard_probe tools/cvt_probe tools/sign_probe
 tools: $(TOOLS)
 tools/%: tools/%.hip $(HIP_HDRS)
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -Iinclude -o $@ $<
