@@ -1256,6 +1256,10 @@ static int render_batch(rt_ctx *ctx, const Uniforms *u, const Object *objs, int 
         chunk = (int)std::lround(std::max(0.4 * per_lane, std::min(2.0 * per_lane, std::sqrt(4000.0 * per_lane / objects))));
         chunk = std::max(1, std::min(64, chunk));
         if (chunk >= 6) chunk = std::min(64, (chunk + 2) & ~3);  // whole planes of 4 samples (below)
+        // The wavefront kernels run as many bounce steps as the slot with the most segments needs, and a slot works its
+        // item's samples off one after the other: short items (a sample each up to 64 samples per pixel, so that there
+        // are at most 64 planes) make the launch 2.2 times shorter on the nested shells and 1.2 on the cover scene.
+        if (ctx->opt_kernel == 1) chunk = std::max(1, (nrays + 63) / 64);
     }
     // A tail of short items after the long ones lets the grid drain more evenly, but on the cover scene it costs
     // more in ray generation than it gains (1 to 2 %): off unless asked for.

@@ -9,6 +9,8 @@ objs, n = rt.scene(os.environ.get("SCENE", "cover"))
 r.setupTexture(w, h)
 r.setScene(objs, n)
 r.set_option(rt.RT_OPT_KERNEL, 1)
+if os.environ.get("CHUNK"):
+    r.set_option(rt.RT_OPT_CHUNK, int(os.environ["CHUNK"]))
 if os.environ.get("SLOTS"):
     r.set_option(rt.RT_OPT_WAVEFRONT_SLOTS, int(os.environ["SLOTS"]))
 u = rt.config_uniforms(os.environ.get("SCENE", "cover"), w, h, spp, int(os.environ.get("DEPTH", "50")), n)
