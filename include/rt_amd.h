@@ -100,6 +100,10 @@ enum {
                                them (short paths) goes back to an item per lane.  Results are identical.  Measured: one
                                rank's share of the benchmark frame at 8 ranks +0.4 %, nested shells +1.3 %, Cornell box -4 %,
                                hence not the default */
+    RT_OPT_NARROW = 14,     /* staged matrix-core kind: 1 (default) = where at most 32 rays of a wave can touch the box around the
+                               scene's ordinary spheres, the sphere filter runs on those rays alone, at half width (scenes of 128
+                               spheres or more with at most 8 spheres much larger than the rest); 0 = always at full width.
+                               Results are identical */
     RT_OPT_REGROUP = 11     /* material scatter of the staged matrix kind's batch kernels (results are identical):
                                0 = automatic (default), 1 = every lane scatters its own path, 2 = requests are sorted by
                                material over the workgroup through LDS, so that a wave runs one branch of the material

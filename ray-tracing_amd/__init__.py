@@ -100,6 +100,7 @@ class Stats(C.Structure):
 
 RT_OPT_CHUNK, RT_OPT_KERNEL, RT_OPT_SCENE_FETCH, RT_OPT_BLOCKS_PER_CU, RT_OPT_FILTER, RT_OPT_WAVEFRONT_SLOTS = 1, 3, 4, 5, 6, 7
 RT_OPT_TAIL_CHUNK, RT_OPT_TAIL_SAMPLES, RT_OPT_RESOLVE, RT_OPT_REGROUP, RT_OPT_PLANE_SAMPLES, RT_OPT_SHARE = 8, 9, 10, 11, 12, 13
+RT_OPT_NARROW = 14
 RT_NOALLOC_PLANE_BYTES = 64 << 20  # include/rt_amd.h
 
 # Every symbol include/rt_amd.h declares.

@@ -26,6 +26,14 @@ struct DevBuf {
     T *ptr = nullptr;
     size_t cap = 0;  // elements
 };
+// What the staged matrix kind needs to run its filter at half width (TraceParams::narrow ..., narrow_setup).
+struct NarrowSet {
+    bool ok = false;
+    float oo = 0.0f;
+    V3 mid = {0.0f, 0.0f, 0.0f}, half = {0.0f, 0.0f, 0.0f};
+    int words = 0;
+    uint32_t word[kWideWords] = {}, test[kWideWords] = {}, always[kWideWords] = {};
+};
 }  // namespace
 
 // Scratch of rt_render_noalloc: device memory that belongs to the library itself, so that entry point never has to
@@ -72,6 +80,7 @@ struct rt_ctx {
     LiftFrame lift = {0.0f, 0.0f, 0.0f, 1.0f};
     float oo_limit_m = -1.0f;  // origin limit of the matrix-core filter in the lifted frame; < 0: scene not eligible
     int matrix_outliers = 0;   // spheres the matrix-core filter always passes on to the exact test
+    NarrowSet narrow;          // the staged matrix kind at half width (narrow_setup)
     DevBuf<int> sph_obj;
     DevBuf<QuadDev> quads;
     DevBuf<MatDev> mats;
@@ -100,6 +109,7 @@ struct rt_ctx {
     int opt_regroup = 0;
     int opt_plane = -1;
     int opt_share = 1;   // RT_OPT_SHARE
+    int opt_narrow = 1;  // RT_OPT_NARROW
     int opt_wf_slots = 1 << 20;
 
     rt_stats last = {};
@@ -248,6 +258,85 @@ struct TileBuilder {
         split(begin + left, end);
     }
 };
+// The staged matrix kind at half width (rt_hit.hpp filter_round_narrow): a box around the scene's ordinary spheres, such
+// that a ray that cannot touch it has no candidate among them, and the list of the others -- spheres much larger than
+// the ordinary ones, which would blow the box up, and spheres the lifted form cannot hold (candidates for every ray).
+//   ordinary: lifted, finite, radius <= 4 x the median radius.  The others may fill bits of at most kWideWords words
+//     and number at most 8 (each costs every ray a turn of the vector filter), else the scene does without.
+//   origins: the box test speaks for rays whose origin lies within O = 4 x the largest |c - T| + r of an ordinary sphere
+//     of the frame's centre T (or the lifted form's own limit if that is smaller); rays from farther away count as
+//     touching.  D = O + max |c - T| then bounds |o - c|.
+//   padding: whenever the reference's discriminant is >= 0 the ray's line passes within sqrt(r^2 + 17u D^2) of the
+//     centre, u = 2^-24, and an accepted root's point lies within sqrt(r^2 + 34u D^2); every radius is grown to
+//     sqrt(r^2 + 40u D^2).  The test's own roundings: its cross products err by <= 4u E (|d_a| + |d_b|) with
+//     E >= |o - mid| per axis, which 2^-16 E added to every half extent covers sixteen times over; the products with
+//     the half extents err by 4u relative, covered by the factor 1 + 2^-12.
+NarrowSet narrow_setup(const std::vector<float4> &sph, int nsph, const std::vector<char> &lifted_ok, const LiftFrame &frame, float oo_limit_m) {
+    NarrowSet N;
+    if (nsph < 128 || oo_limit_m <= 0.0f || (int)lifted_ok.size() < nsph) return N;
+    std::vector<float> radii;
+    for (int i = 0; i < nsph; ++i)
+        if (lifted_ok[(size_t)i]) radii.push_back(sph[(size_t)i].w);
+    if (radii.size() < (size_t)nsph / 2) return N;
+    std::nth_element(radii.begin(), radii.begin() + (long)(radii.size() / 2), radii.end());
+    const double rmed = radii[radii.size() / 2];
+    const double T[3] = {frame.tx, frame.ty, frame.tz};
+    auto ordinary = [&](int i) {
+        const float4 &q = sph[(size_t)i];
+        return lifted_ok[(size_t)i] && std::isfinite(q.x) && std::isfinite(q.y) && std::isfinite(q.z) && std::isfinite(q.w) &&
+               (double)q.w <= 4.0 * rmed;
+    };
+    int others = 0;
+    double cmax = 0.0, reach = 0.0;
+    for (int i = 0; i < nsph; ++i) {
+        const float4 &q = sph[(size_t)i];
+        if (!ordinary(i)) {
+            const uint32_t w = (uint32_t)i / 32u, bit = 0x80000000u >> ((uint32_t)i & 31u);
+            int k = 0;
+            while (k < N.words && N.word[k] != w) ++k;
+            if (k == kWideWords || ++others > 8) return N;
+            if (k == N.words) N.word[N.words++] = w;
+            // a sphere that can never be hit (no finite record) needs no look at all
+            const bool finite = std::isfinite(q.x) && std::isfinite(q.y) && std::isfinite(q.z) && std::isfinite(q.w);
+            if (finite) (lifted_ok[(size_t)i] ? N.test[k] : N.always[k]) |= bit;
+            continue;
+        }
+        const double dx = (double)q.x - T[0], dy = (double)q.y - T[1], dz = (double)q.z - T[2];
+        const double c = std::sqrt(dx * dx + dy * dy + dz * dz);
+        cmax = std::max(cmax, c);
+        reach = std::max(reach, c + std::fabs((double)q.w));
+    }
+    const double o_lifted = std::sqrt((double)oo_limit_m) / (double)frame.sigma;
+    const double O = std::min(4.0 * reach, o_lifted);
+    const double D = O + cmax;
+    const double grow = 40.0 * 0x1p-24 * D * D;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int i = 0; i < nsph; ++i) {
+        if (!ordinary(i)) continue;
+        const float4 &q = sph[(size_t)i];
+        const double r = std::sqrt((double)q.w * (double)q.w + grow);
+        const double c[3] = {q.x, q.y, q.z};
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], c[a] - r);
+            hi[a] = std::max(hi[a], c[a] + r);
+        }
+    }
+    float mid[3], half[3];
+    for (int a = 0; a < 3; ++a) {
+        mid[a] = (float)(0.5 * (lo[a] + hi[a]));
+        const double E = O + std::fabs((double)mid[a] - T[a]);
+        const double h = (std::max(hi[a] - (double)mid[a], (double)mid[a] - lo[a])) * (1.0 + 0x1p-12) + 0x1p-16 * E;
+        half[a] = std::nextafterf((float)h, std::numeric_limits<float>::infinity());
+        if (!std::isfinite(mid[a]) || !std::isfinite(half[a])) return N;
+    }
+    N.mid.x = mid[0]; N.mid.y = mid[1]; N.mid.z = mid[2];
+    N.half.x = half[0]; N.half.y = half[1]; N.half.z = half[2];
+    const double oo = O * (double)frame.sigma * (O * (double)frame.sigma) * (1.0 - 0x1p-10);
+    N.oo = (float)std::min(oo, (double)oo_limit_m);
+    N.ok = true;
+    return N;
+}
+
 TileSet build_tiles(const std::vector<float4> &sph, const std::vector<int> &sph_obj, int nsph) {
     TileSet T;
     if (nsph <= 0) return T;
@@ -672,6 +761,7 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n, bool *cache_hit = nullp
     LiftFrame frame = {0.0f, 0.0f, 0.0f, 1.0f};
     float oo_limit_m = -1.0f;
     int outliers = 0;
+    std::vector<char> lifted_ok;
     if (nsph > 0) {
         std::vector<float> med[3];
         for (int i = 0; i < nsph; ++i) {
@@ -700,11 +790,13 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n, bool *cache_hit = nullp
         const int nblocks = (nsph + 63) / 64;
         sphm.assign((size_t)nblocks * 64 * kLiftSlots, (_Float16)0.0f);
         std::vector<double> room;
+        lifted_ok.assign((size_t)nsph, 0);
         for (int i = 0; i < nblocks * 64; ++i) {
             _Float16 slots[kLiftSlots];
             if (i < nsph) {
                 const float4 &q = sph[(size_t)i];
                 if (lift_sphere(q.x, q.y, q.z, q.w, frame, (double)kMfmaSlack, slots)) {
+                    lifted_ok[(size_t)i] = 1;
                     const double g = frame.sigma;
                     const double x = ((double)q.x - t[0]) * g, y = ((double)q.y - t[1]) * g, z = ((double)q.z - t[2]) * g, r2 = (double)q.w * g * ((double)q.w * g);
                     room.push_back(r2 / (double)kMfmaSlack - (x * x + y * y + z * z) - r2);
@@ -723,6 +815,7 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n, bool *cache_hit = nullp
             if (lim > 0.0) oo_limit_m = (float)lim;
         }
     }
+    const NarrowSet narrow = narrow_setup(sph, nsph, lifted_ok, frame, oo_limit_m);
     TileSet tileset = build_tiles(sph, sph_obj, nsph);
     while ((int)sph.size() < nslots) {
         sph.push_back(make_float4(0.0f, 0.0f, 0.0f, std::numeric_limits<float>::quiet_NaN()));    // never a hit
@@ -749,6 +842,7 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n, bool *cache_hit = nullp
     ctx->lift = frame;
     ctx->oo_limit_m = oo_limit_m;
     ctx->matrix_outliers = outliers;
+    ctx->narrow = narrow;
     ctx->ntiles = tileset.ntiles;
     ctx->tiles_ok = tileset.ok;
     ctx->scene_dense = dense_scene(sph, nsph) && balls_nested(balls);
@@ -813,6 +907,16 @@ void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
     P.fine_plane0 = 0;
     P.share_begin = 0xFFFFFFFFu;
     P.regroup = ctx->opt_regroup == 2 && ctx->opt_kernel != 1 ? 1 : 0;
+    P.narrow = ctx->narrow.ok && ctx->opt_narrow != 0 ? 1 : 0;
+    P.narrow_oo = ctx->narrow.oo;
+    P.cull_mid = ctx->narrow.mid;
+    P.cull_half = ctx->narrow.half;
+    P.wide_words = ctx->narrow.words;
+    for (int k = 0; k < kWideWords; ++k) {
+        P.wide_word[k] = ctx->narrow.word[k];
+        P.wide_test[k] = ctx->narrow.test[k];
+        P.wide_always[k] = ctx->narrow.always[k];
+    }
     P.dense_kernel = ctx->opt_resolve == 2 || (ctx->opt_resolve == 0 && ctx->scene_dense) ? 1 : 0;
     P.width = ctx->width;
     P.height = ctx->height;
@@ -1054,6 +1158,10 @@ RT_API int rt_set_option(rt_ctx *ctx, int key, int value) {
             if (value < 0 || value > 1) return fail(ctx, RT_ERR_INVALID, "rt: share must be 0 or 1");
             ctx->opt_share = value;
             return RT_OK;
+        case RT_OPT_NARROW:
+            if (value < 0 || value > 1) return fail(ctx, RT_ERR_INVALID, "rt: narrow must be 0 or 1");
+            ctx->opt_narrow = value;
+            return RT_OK;
         case RT_OPT_REGROUP:
             if (value < 0 || value > 2) return fail(ctx, RT_ERR_INVALID, "rt: regroup must be 0, 1 or 2");
             ctx->opt_regroup = value;
@@ -1080,6 +1188,7 @@ RT_API int rt_get_option(const rt_ctx *ctx, int key, int *value) {
         case RT_OPT_REGROUP: *value = ctx->opt_regroup; return RT_OK;
         case RT_OPT_PLANE_SAMPLES: *value = ctx->opt_plane; return RT_OK;
         case RT_OPT_SHARE: *value = ctx->opt_share; return RT_OK;
+        case RT_OPT_NARROW: *value = ctx->opt_narrow; return RT_OK;
         case RT_OPT_WAVEFRONT_SLOTS: *value = ctx->opt_wf_slots; return RT_OK;
     }
     return RT_ERR_INVALID;
@@ -1432,7 +1541,7 @@ RT_API int rt_last_stats(rt_ctx *ctx, rt_stats *out) {
         ctx->last.tests = seg * (uint64_t)ctx->nobj;
         for (int i = 0; i < 8; ++i) ctx->last.phase_cycles[i] = (uint64_t)host[4 + 2 * i] | ((uint64_t)host[5 + 2 * i] << 32);
         ctx->last.wave_trips = (uint64_t)host[20] | ((uint64_t)host[21] << 32);
-        ctx->last.matrix_blocks = (uint64_t)host[22] | ((uint64_t)host[23] << 32);
+        ctx->last.matrix_blocks = ((uint64_t)host[22] | ((uint64_t)host[23] << 32)) / 2u;  // counted in halves (rt_hit.hpp Work)
         ctx->stats_pending = false;
     }
     *out = ctx->last;

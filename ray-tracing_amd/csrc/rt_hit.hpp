@@ -231,7 +231,8 @@ struct Prof {
 // Executed-work counters of one wave, always on (wave-uniform values: scalar registers): closest-hit searches the wave
 // took part in, and 64-sphere blocks it put through the matrix-core filter (8 matrix instructions each).
 struct Work {
-    uint32_t trips = 0, blocks = 0;
+    uint32_t trips = 0, blocks = 0;  // blocks: in halves (four matrix instructions: one ray tile against 64 spheres)
+    uint32_t wide_waves = 0;  // (matrix kind) searches in a row in which more than 32 rays touched the box of the half-width filter
     uint32_t unpaid = 0; // (DENSE kernels) rounds in a row in which resolve_dense_words did not pay, up to 4 (closest_sphere)
     int last_slot = 0;   // per lane (the only member that is): the sphere slot this lane's path hit last (dense rounds
                          // resolve the candidates next to it first)
@@ -367,9 +368,8 @@ RT_DEV void swap_halves(h8 &x0, h8 &x1) {
     x1 = __builtin_bit_cast(h8, b);
 }
 
-// The ten ray-side values -> FP16 pairs in slot order -> the four B operands (the two halves of the wave exchange
-// their slot vectors).
-RT_DEV void pack_lifted(float (&v)[10], RayLifted &L) {
+// The ten ray-side values -> FP16 pairs in slot order: every lane the 32 slots of its own ray, x[i] = slots 8i .. 8i + 7.
+RT_DEV void pack_lifted_slots(float (&v)[10], h8 (&x)[4]) {
     // The FP16 pairs must satisfy hi + lo = v to 2^-22: pin each v as a binary32 value so that both uses of its
     // conversion round the same number (otherwise the compiler converts one of them straight from the unrounded
     // fused product, and the two halves of the pair can then disagree by a whole FP16 ulp).
@@ -387,18 +387,26 @@ RT_DEV void pack_lifted(float (&v)[10], RayLifted &L) {
         r[6 + 3 * t] = hi;
         r[7 + 3 * t] = (_Float16)(v[1 + t] - (float)hi);
     }
-    h8 x00, x01, x10, x11;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { x00[i] = r[i]; x01[i] = r[8 + i]; x10[i] = r[16 + i]; x11[i] = r[24 + i]; }
-    swap_halves(x00, x01);  // -> K half 0 of ray halves 0 and 1
-    swap_halves(x10, x11);  // -> K half 1
-    L.b00 = x00; L.b10 = x01;
-    L.b01 = x10; L.b11 = x11;
+    for (int i = 0; i < 8; ++i) { x[0][i] = r[i]; x[1][i] = r[8 + i]; x[2][i] = r[16 + i]; x[3][i] = r[24 + i]; }
+}
+// Per-lane slot vectors -> the four B operands of the wave's 64 rays (the two halves of the wave exchange them).
+RT_DEV void exchange_lifted(h8 (&x)[4], RayLifted &L) {
+    swap_halves(x[0], x[1]);  // -> K half 0 of ray halves 0 and 1
+    swap_halves(x[2], x[3]);  // -> K half 1
+    L.b00 = x[0]; L.b10 = x[1];
+    L.b01 = x[2]; L.b11 = x[3];
+}
+RT_DEV void pack_lifted(float (&v)[10], RayLifted &L) {
+    h8 x[4];
+    pack_lifted_slots(v, x);
+    exchange_lifted(x, L);
 }
 
-// Ray side of the lifted form, every lane for its own ray, then the exchange that turns the per-lane slot vectors
-// into the four B operands.  oo is |o'|^2 in the scaled frame (the caller compares it with the scene's limit).
-RT_DEV void lift_ray(const LiftFrame &F, V3 o, V3 dn, float slack, float &oo, RayLifted &L) {
+// Ray side of the lifted form, every lane for its own ray: the slot vectors (lift_ray_slots), or those already
+// exchanged into the four B operands (lift_ray).  oo is |o'|^2 in the scaled frame (the caller compares it with the
+// scene's limit).
+RT_DEV void lift_ray_slots(const LiftFrame &F, V3 o, V3 dn, float slack, float &oo, h8 (&x)[4]) {
     const float ox = (o.x - F.tx) * F.sigma, oy = (o.y - F.ty) * F.sigma, oz = (o.z - F.tz) * F.sigma;
     oo = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
     const float odn = __builtin_fmaf(oz, dn.z, __builtin_fmaf(oy, dn.y, ox * dn.x));
@@ -409,7 +417,12 @@ RT_DEV void lift_ray(const LiftFrame &F, V3 o, V3 dn, float slack, float &oo, Ra
     v[3] = 2.0f * __builtin_fmaf(-odn, dn.z, oz);
     v[4] = dn.x * dn.x; v[5] = dn.y * dn.y; v[6] = dn.z * dn.z;
     v[7] = dn.x * dn.y; v[8] = dn.x * dn.z; v[9] = dn.y * dn.z;
-    pack_lifted(v, L);
+    pack_lifted_slots(v, x);
+}
+RT_DEV void lift_ray(const LiftFrame &F, V3 o, V3 dn, float slack, float &oo, RayLifted &L) {
+    h8 x[4];
+    lift_ray_slots(F, o, dn, slack, oo, x);
+    exchange_lifted(x, L);
 }
 
 // The same for a frame that is local to a tile of spheres while the ray may start far away (tiled kind).  The
@@ -532,6 +545,82 @@ RT_DEV uint32_t filter_round_matrix(const h8 *pm, int blk0, int blk1, uint32_t *
         nz |= ((b1 << 1) | b0) << w;
     }
     return nz;
+}
+
+// ---- the matrix-core filter at half width ---------------------------------------------------------------------
+// Most rays of a scene whose small spheres lie in a thin layer (the cover scene: a field of spheres of radius 0.2 on
+// the ground) pass that layer by: their line misses the bounding box of those spheres, so no sphere inside it can be
+// a candidate, and the filter has nothing to find out about them.  When at most 32 lanes of a wave hold a ray that
+// does touch the box, those rays are moved into the 32 columns of ONE ray tile -- lane l and lane l + 32 supply K
+// slots 0-7 and 8-15 of the ray in column l % 32 -- and a 64-sphere block costs four matrix instructions and 32
+// sign extractions instead of eight and 64.  The spheres the box leaves out (few and large, or not representable in
+// the lifted form; the host lists them) are tested for every ray by the general vector filter afterwards.
+//
+// Conservativeness.  Whenever the reference's discriminant is >= 0 the ray's line passes within
+// sqrt(r^2 + 17u |o - c|^2) of the centre (closest_sphere), and the accepted root's point lies within the same
+// distance of it up to another 17u |o - c|^2 under the root; the host grows every sphere's radius to
+// sqrt(r^2 + 40u D^2) with D >= |o - c| for every origin this path admits (TraceParams::narrow_oo) before it takes the
+// box, and pads the box for the roundings of the test itself (rt_api.hip narrow_setup).  The test declares a miss only
+// on a separating axis of line and box (the three cross products of the direction with the box axes) or when the
+// origin lies outside a slab and the ray does not move towards it; every comparison is false on a NaN operand, so
+// such a ray counts as touching.
+
+// May the ray (o, d), t >= 0, touch the box with centre m and half extents h?
+RT_DEV bool ray_may_touch_box(V3 o, V3 d, V3 m, V3 h) {
+    const float ex = o.x - m.x, ey = o.y - m.y, ez = o.z - m.z;
+    const float adx = __builtin_fabsf(d.x), ady = __builtin_fabsf(d.y), adz = __builtin_fabsf(d.z);
+    // separating axes d x e_i
+    bool miss = __builtin_fabsf(__builtin_fmaf(ey, d.z, -(ez * d.y))) > __builtin_fmaf(h.y, adz, h.z * ady);
+    miss = miss || __builtin_fabsf(__builtin_fmaf(ez, d.x, -(ex * d.z))) > __builtin_fmaf(h.z, adx, h.x * adz);
+    miss = miss || __builtin_fabsf(__builtin_fmaf(ex, d.y, -(ey * d.x))) > __builtin_fmaf(h.x, ady, h.y * adx);
+    // outside a slab and not moving towards it
+    miss = miss || (__builtin_fabsf(ex) > h.x && ex * d.x >= 0.0f);
+    miss = miss || (__builtin_fabsf(ey) > h.y && ey * d.y >= 0.0f);
+    miss = miss || (__builtin_fabsf(ez) > h.z && ez * d.z >= 0.0f);
+    return !miss;
+}
+
+// Two 32-sphere groups against one ray tile: q0 = group 0, q1 = group 1 (fenced and read like matrix_group).
+RT_DEV void matrix_pair(const h8 a0_lo, const h8 a0_hi, const h8 a1_lo, const h8 a1_hi, const h8 b_lo, const h8 b_hi, f32x16 &q0,
+                        f32x16 &q1) {
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#if !defined(RT_NO_MFMA_FENCE) || (RT_NO_MFMA_FENCE & 1)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    q0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0_lo, b_lo, zero, 0, 0, 0);
+    q1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1_lo, b_lo, zero, 0, 0, 0);
+    q0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0_hi, b_hi, q0, 0, 0, 0);
+    q1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1_hi, b_hi, q1, 0, 0, 0);
+#if !defined(RT_NO_MFMA_FENCE) || (RT_NO_MFMA_FENCE & 2)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+// Pass A over 64-sphere blocks [blk0, blk1) for the rays of one tile: b_lo / b_hi are this lane's B operands (column
+// lane % 32 of the tile, K slots 8 (lane / 32) .. + 7 of each K half), `owner` the lane whose ray the column holds.
+// Lane half h ends up with word 2 blk + h of its column's ray -- the rows a lane half receives are the spheres of one
+// word (lift_index) -- and writes it straight into the owner's place.  Returns the bitmap of the non-empty words this
+// lane wrote (the owner needs the OR over both halves of its column).
+RT_DEV uint32_t filter_round_narrow(const h8 *pm, int blk0, int blk1, uint32_t *masks, int lane, const h8 b_lo, const h8 b_hi, int owner,
+                                    bool column_used) {
+    uint32_t nz = 0;
+    const h8 *A = pm + (size_t)blk0 * 256 + lane;
+    const int h = lane >> 5;
+    for (int blk = blk0, w = 0; blk < blk1; ++blk, w += 2, A += 256) {
+        f32x16 q0, q1;
+        uint32_t word = 0;
+        matrix_pair(A[0], A[64], A[128], A[192], b_lo, b_hi, q0, q1);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) word = push_sign(word, q0[k]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) word = push_sign(word, q1[k]);
+        const uint32_t c = ~word;
+        if (column_used) masks[(w + h) * 64 + owner] = c;
+        uint32_t b;
+        asm("v_min_u32 %0, 1, %1" : "=v"(b) : "v"(c));
+        nz |= b << (w + h);
+    }
+    return column_used ? nz : 0u;
 }
 
 // Pass B for slots that are in object order, balanced over the wave.  Lanes differ in how many candidates pass A left
@@ -1284,19 +1373,62 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
     const RootDiv dv = root_div(a, active);
     const float s = __builtin_amdgcn_rsqf(a) * kDirScale;
     const V3 dn = v3(d.x * s, d.y * s, d.z * s);
+    const int lane = threadIdx.x & 63;
     float oo;
     RayLifted lifted;
+    h8 slots[4];
     if constexpr (F::kMatrix) {
-        lift_ray(P.lift, o, dn, kMfmaSlack, oo, lifted);
+        lift_ray_slots(P.lift, o, dn, kMfmaSlack, oo, slots);
     } else {
         oo = __builtin_fmaf(o.z, o.z, __builtin_fmaf(o.y, o.y, o.x * o.x));
     }
     const bool general = __builtin_amdgcn_ballot_w64(active && !(oo <= P.oo_limit)) != 0;  // wave-uniform
-    const int lane = threadIdx.x & 63;
     // every lane's closest (distance, slot) so far, kept in LDS where other lanes can lower it (resolve_balanced)
     unsigned long long *best = (unsigned long long *)(wave_masks + kBestOffset);
     best[lane] = ((unsigned long long)__float_as_uint(tbest) << 32) | 0xFFFFFFFFull;
     f.start(general);
+    // Matrix kind: the filter at half width when at most 32 rays of the wave can touch the box of the scene's small
+    // spheres (filter_round_narrow).  The rays that can are moved into one ray tile through the (still unused)
+    // candidate-word area: a lane with such a ray writes its slot vectors to row `rank` (its number among those lanes)
+    // and its lane number to the list; lanes l and l + 32 then read the K slots they supply for the ray of row l % 32.
+    uint64_t touching = 0;
+    bool narrow = false;
+    int owner = lane;
+    if constexpr (F::kMatrix) {
+        if (P.narrow != 0 && !general && work.wide_waves < 4u) {
+            const bool touch = active && a_ok && (!(oo <= P.narrow_oo) || ray_may_touch_box(o, d, P.cull_mid, P.cull_half));
+            touching = __builtin_amdgcn_ballot_w64(touch);
+            const int n = __builtin_popcountll(touching);
+            narrow = n <= 32;
+            work.wide_waves = narrow ? 0u : work.wide_waves + 1u;
+            if (narrow) {
+                typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                u4 *rows = (u4 *)wave_masks;
+                uint32_t *list = wave_masks + kListOffset;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(touching >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)touching, 0u));
+                if (touch) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rows[rank * 4u + (uint32_t)i] = __builtin_bit_cast(u4, slots[i]);
+                    list[rank] = (uint32_t)lane;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int col = lane & 31, half = lane >> 5;
+                lifted.b00 = __builtin_bit_cast(h8, rows[col * 4 + half]);
+                lifted.b01 = __builtin_bit_cast(h8, rows[col * 4 + 2 + half]);
+                owner = (int)list[col];
+                // (the words are written only after these reads have returned: LDS operations of a wave execute in order)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        } else if (P.narrow != 0 && !general) {
+            // a wave most of whose rays touch the box stops asking for a while
+            work.wide_waves = (work.wide_waves + 1u) & 31u;
+        }
+        if (!narrow) exchange_lifted(slots, lifted);
+    }
     for (int g0 = 0; g0 < P.ngroups; g0 += kRoundWords * kWordGroups) {
         const int g1 = min(P.ngroups, g0 + kRoundWords * kWordGroups);
         uint32_t nz;
@@ -1307,9 +1439,40 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
             // The filter is long bursts of matrix and vector issue, everything else in a trip is short dependent
             // chains: a wave outside the filter goes first when it has an instruction ready (+2.8 % measured).
             __builtin_amdgcn_s_setprio(0);
-            nz = filter_round_matrix(f.pm, g0 / 16, (g1 + 15) / 16, wave_masks, lane, lifted);
+            const int blk0 = g0 / 16, blk1 = (g1 + 15) / 16;
+            if (narrow) {
+                nz = 0;
+                if (touching != 0) {
+                    const int n = __builtin_popcountll(touching);
+                    uint32_t *list = wave_masks + kListOffset;
+                    list[lane] = filter_round_narrow(f.pm, blk0, blk1, wave_masks, lane, lifted.b00, lifted.b01, owner, (lane & 31) < n);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(touching >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)touching, 0u));
+                    if ((touching >> lane) & 1ull) nz = list[rank] | list[rank + 32u];
+                    work.blocks += (uint32_t)(blk1 - blk0);
+                }
+                // the spheres the box does not stand for, every lane for its own ray
+                const RayGeneral y = {o, dn};
+                for (int k = 0; k < P.wide_words; ++k) {
+                    const int w = (int)P.wide_word[k] - g0 / kWordGroups;
+                    if (w < 0 || w >= kRoundWords) continue;
+                    uint32_t m = (nz >> w) & 1u ? wave_masks[w * 64 + lane] : 0u;
+                    m |= P.wide_always[k];
+                    for (uint32_t t = P.wide_test[k]; t != 0; t &= t - 1) {
+                        const int j = 31 - __builtin_ctz(t);  // bit 31 - j is slot 32 w + j
+                        const float q = sphere_q(f.load1(4 * g0 + 32 * w + j), y);
+                        m |= (~__float_as_uint(q) & 0x80000000u) >> j;
+                    }
+                    wave_masks[w * 64 + lane] = m;
+                    nz |= (m != 0u ? 1u : 0u) << w;
+                }
+            } else {
+                nz = filter_round_matrix(f.pm, blk0, blk1, wave_masks, lane, lifted);
+                work.blocks += 2u * (uint32_t)(blk1 - blk0);
+            }
             __builtin_amdgcn_s_setprio(1);
-            work.blocks += (uint32_t)((g1 + 15) / 16 - g0 / 16);
         } else {
             RayCompact y;
             y.ndnx = -dn.x; y.ndny = -dn.y; y.ndnz = -dn.z;
@@ -1422,7 +1585,7 @@ RT_DEV int closest_sphere_tiled(const TraceParams &P, Fetch<kFetchTiled> &f, uin
             else
                 nz = filter_round_matrix<false>((const h8 *)tile, 0, (count + 63) / 64, wave_masks, lane, lifted);
             __builtin_amdgcn_s_setprio(1);
-            work.blocks += (uint32_t)((count + 63) / 64);
+            work.blocks += 2u * (uint32_t)((count + 63) / 64);
         }
         if (!a_ok || !active) nz = 0;
         prof.lap(1);

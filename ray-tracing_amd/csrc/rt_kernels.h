@@ -11,6 +11,7 @@ namespace rt {
 
 enum { kModeAccum = 0, kModeProgressive = 1 };
 constexpr int kBoundVec4 = 10;  // float4 of bounding balls per word of 32 sphere slots (TraceParams::word_bounds)
+constexpr int kWideWords = 4;  // words of 32 sphere slots that may hold spheres outside the box of the half-width filter (TraceParams::wide_word)
 constexpr int kQueueRays = 64;  // camera rays per lane in the trace kernel's per-wave queue (two float4 each)
 
 // Tiled matrix-core kind (TraceParams::tiles, rt_hit.hpp closest_sphere_tiled).
@@ -56,6 +57,16 @@ struct TraceParams {
     const float4 *round_runs;   // two float4 per resolve round of 512 slots: (centre, bits of first slot | end slot << 16 of the run)
                                 // and (bits of the round's words of that run | its words with exempt slots << 16, 2 if the radii
                                 // fall along the slots else 3, 0, 0); no words when the round's words of runs are not all of one run
+    // Staged matrix kind at half width (rt_hit.hpp filter_round_narrow; rt_api.hip narrow_setup).  narrow != 0: a ray whose
+    // origin lies within narrow_oo (|o'|^2 in the lifted frame) and that cannot touch the box (cull_mid, cull_half) has
+    // no candidate among the spheres the box stands for.  The others -- the spheres of bits wide_test[k] (tested with the
+    // general vector filter) and wide_always[k] (candidates for every ray) of word wide_word[k] = slot / 32, bit 31 - j
+    // for slot 32 w + j -- are looked at for every ray.
+    int narrow;
+    float narrow_oo;
+    V3 cull_mid, cull_half;
+    int wide_words;
+    uint32_t wide_word[kWideWords], wide_test[kWideWords], wide_always[kWideWords];
     float4 *rayq;           // per-wave queues of generated camera rays: grid lanes x kQueueRays x 2 float4
     int maxDepth;           // Uniforms.maxRayDepth
     V4 sky;                 // Uniforms.globalIllumation

@@ -967,6 +967,114 @@ def test_random_scenes_matrix_equals_vector(rt, renderer, seed, extent, offset):
     assert np.array_equal(bits(tiled), bits(imgs[2]))
 
 
+def _layer_scene(rt, case):
+    """Scenes for the half-width sphere filter: many small spheres in a layer, a few large ones and a ground sphere.
+    Returns (objects, camera position, look-at, whether the half-width path must have run)."""
+    rng = np.random.default_rng({"cover_like": 11, "wide_in_the_middle": 12, "camera_in_the_layer": 13, "far_camera": 14,
+                                 "too_many_wide": 15, "two_rounds": 16, "thick_cloud": 17}[case])
+    n_small = 700 if case == "two_rounds" else 300
+    extent = 12.0
+
+    def material():
+        kind = rng.random()
+        if kind < 0.6:
+            return rt.SwiftMaterial.lambertian(*rng.random(3))
+        if kind < 0.8:
+            return rt.SwiftMaterial.metal(*(0.5 + 0.5 * rng.random(3)), 0.3 * rng.random())
+        return rt.SwiftMaterial.dielectric(1.5)
+
+    small = []
+    for i in range(n_small):
+        r = float(rng.uniform(0.08, 0.3))
+        y = r if case != "thick_cloud" else float(rng.uniform(0.0, 6.0))
+        small.append(rt.makeSphere((float(rng.uniform(-extent, extent)), y, float(rng.uniform(-extent, extent))), r, material()))
+    ground = rt.makeSphere((0.0, -1000.0, 0.0), 1000.0, rt.SwiftMaterial.lambertian(0.5, 0.5, 0.5))
+    large = [rt.makeSphere((0.0, 1.0, 0.0), 1.0, rt.SwiftMaterial.dielectric(1.5)),
+             rt.makeSphere((-4.0, 1.0, 0.0), 1.0, rt.SwiftMaterial.lambertian(0.4, 0.2, 0.1)),
+             rt.makeSphere((4.0, 1.0, 0.0), 1.0, rt.SwiftMaterial.metal(0.7, 0.6, 0.5, 0.0)),
+             rt.makeSphere((0.0, 2.5, -5.0), 2.5, rt.SwiftMaterial.dielectric(1.3))]
+    eye, look, narrow = (13.0, 2.0, 3.0), (0.0, 0.0, 0.0), True
+    if case in ("cover_like", "thick_cloud"):
+        objs = [ground] + small + large[:3]
+        narrow = case == "cover_like"     # a cloud six units thick: most rays touch its box
+    elif case == "wide_in_the_middle":    # the large spheres and the ground in three words in the middle of the slots
+        objs = small[:70] + large[:2] + small[70:200] + [ground] + small[200:290] + large[2:] + small[290:]
+    elif case == "camera_in_the_layer":   # rays that run along the top of the box, a camera between the small spheres
+        objs = [ground] + small + large[:3]
+        eye, look = (9.0, 0.35, 2.0), (-3.0, 0.3, -1.0)
+    elif case == "far_camera":            # origins beyond what the box test speaks for, and beyond the lifted form's range
+        objs = [ground] + small + large[:3]
+        eye = (2600.0, 400.0, 600.0)
+    elif case == "too_many_wide":         # nine spheres outside the box: the scene does without the half-width path
+        more = [rt.makeSphere((float(6 * np.cos(a)), 1.5, float(6 * np.sin(a))), 1.5, material()) for a in np.arange(5) * 1.2]
+        objs = [ground] + small + large + more
+        narrow = False
+    else:                                 # two resolve rounds of 512 slots, large spheres in both
+        objs = small[:100] + large[:2] + small[100:600] + [ground] + large[2:] + small[600:]
+    return objs, eye, look, narrow
+
+
+@pytest.mark.parametrize("case", ["cover_like", "wide_in_the_middle", "camera_in_the_layer", "far_camera", "too_many_wide", "two_rounds",
+                                  "thick_cloud"])
+def test_half_width_filter_bit_exact(rt, oracle, renderer, case):
+    """RT_OPT_NARROW: rays that cannot touch the box around the scene's small spheres are left out of the matrix-core
+    filter, the others share one ray tile.  With it (the default) and without, the image is the oracle's."""
+    strict(renderer, rt)
+    objs, eye, look, narrow = _layer_scene(rt, case)
+    n = len(objs)
+    arr = rt.object_array(objs)
+    w, h, spp = 96, 54, 4
+    u = rt.config_uniforms("cover", w, h, spp, 50, n)
+    f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+    rt.host_lib().rt_camera_setup(C.byref(u), f3(eye), f3(look), f3([0, 1, 0]), 25.0, 0.4, 10.0, w, h)
+    renderer.setupTexture(w, h)
+    want = oracle.image(u, arr, w, h)
+    per_trip = {}
+    try:
+        for opt in (1, 0):
+            renderer.set_option(rt.RT_OPT_NARROW, opt)
+            img = renderer.renderImage(u, arr, n)
+            st = renderer.lastStats()
+            assert st.scene_path == 3
+            per_trip[opt] = st.matrix_blocks / st.wave_trips
+            assert np.array_equal(bits(img), bits(want)), (case, opt)
+    finally:
+        renderer.set_option(rt.RT_OPT_NARROW, 1)
+    assert len(np.unique(bits(want).reshape(-1, 4), axis=0)) > 50
+    if narrow and case != "far_camera":
+        assert per_trip[1] < 0.8 * per_trip[0], per_trip   # the half-width path did run
+    if not narrow and case == "too_many_wide":
+        assert per_trip[1] == per_trip[0], per_trip
+
+
+def test_half_width_filter_at_scale(rt, renderer):
+    """Larger than the oracle checks in seconds: the cover scene at 1200x675 x 64 samples with and without the half-width
+    path, and the wavefront kernels with it: the same bits (work items of 16 samples, so that all three add up alike)."""
+    strict(renderer, rt, chunk=16)
+    w, h, spp = 1200, 675, 64
+    objs, n = rt.scene("cover")
+    u = rt.config_uniforms("cover", w, h, spp, 50, n)
+    renderer.setupTexture(w, h)
+    renderer.setScene(objs, n)
+    imgs, per_trip = [], []
+    try:
+        for opt, kernel in ((1, 0), (0, 0), (1, 1)):
+            renderer.set_option(rt.RT_OPT_NARROW, opt)
+            renderer.set_option(rt.RT_OPT_KERNEL, kernel)
+            renderer.accumClear()
+            renderer.render(u, None, 0, 0, spp)
+            renderer.resolve(spp)
+            imgs.append(renderer.readTexture().copy())
+            st = renderer.lastStats()
+            per_trip.append(st.matrix_blocks / st.wave_trips)
+    finally:
+        renderer.set_option(rt.RT_OPT_NARROW, 1)
+        renderer.set_option(rt.RT_OPT_KERNEL, 0)
+    assert np.array_equal(bits(imgs[0]), bits(imgs[1]))
+    assert np.array_equal(bits(imgs[0]), bits(imgs[2]))
+    assert per_trip[0] < 0.6 * per_trip[1] and per_trip[1] == 8.0, per_trip
+
+
 def test_default_path_of_the_cover_scene_is_the_matrix_filter(rt, renderer):
     strict(renderer, rt)
     objs, n = rt.scene("cover")
