@@ -212,7 +212,7 @@ def main():
     # N = 1: the same workload with the vector sphere filter (no matrix instructions), a few steps: the design point
     # whose arithmetic the FP32 vector peak prices
     valu = None
-    if world == 1 and args.valu_steps > 0 and st.scene_path in (3, 4):
+    if world == 1 and args.valu_steps > 0 and st.scene_path in (3, 4, 5):
         r.set_option(rt.RT_OPT_FILTER, 2)
         step()
         fence()
@@ -243,7 +243,7 @@ def main():
         avg_trace_ms = sum(trace_ms) / max(1, len(trace_ms))
         flops_per_launch = FLOPS_PER_TEST * st.tests
         algorithmic = flops_per_launch / (avg_trace_ms * 1e-3) * 1e-12 if avg_trace_ms > 0 else 0.0
-        matrix = st.scene_path in (3, 4)
+        matrix = st.scene_path in (3, 4, 5)
         # Executed matrix work of one launch, counted by the kernel itself: 64-sphere blocks x 64 rays that the waves
         # put through the filter (lanes without a ray ride along), 8 v_mfma_f32_32x32x16_f16 each.
         mfma_flops = MFMA_FLOPS_PER_BLOCK * st.matrix_blocks
@@ -294,7 +294,8 @@ def main():
         roofline.update({
             "sphere_filter": {0: "vector, records staged in LDS", 1: "vector, scalar-cache fetch",
                               2: "vector, streamed tiles", 3: "matrix cores (v_mfma_f32_32x32x16_f16)",
-                              4: "matrix cores, lifted tiles streamed through LDS"}[st.scene_path],
+                              4: "matrix cores, lifted tiles streamed through LDS",
+                              5: "matrix cores, lifted tiles read in place by the waves whose rays can touch them"}[st.scene_path],
             # the reference's brute-force loop priced at 23 flops per ray-object test: a rate of useful work, not a
             # fraction of any pipe once the filter runs on the matrix cores
             "algorithmic_tflops": algorithmic,

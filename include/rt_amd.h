@@ -253,6 +253,16 @@ RT_API int rt_selftest_tiled_filter(rt_ctx *ctx, uint32_t seed, int blocks, int 
  * root the reference computes is not above the ray's bound: both must be 0. */
 RT_API int rt_selftest_prune(rt_ctx *ctx, uint32_t seed, int blocks, int rays_per_thread, uint64_t out[6]);
 
+/* No counterpart in the reference.  Self-test of the box test that lets rays skip the matrix-core sphere filter
+ * (RT_OPT_NARROW), on the scene set with rt_set_scene (RT_ERR_INVALID when the scene has no such box): blocks x 256
+ * threads build rays_per_thread rays each -- origins on or a few ulps off a sphere's surface or a face of the box,
+ * directions tangent to a sphere, at another sphere's silhouette or along a face of the box -- and check every ray the
+ * box test leaves out against the exact hit test (Lib.metal:215-246) of every sphere the box stands for.
+ * padding_log2 = 0 tests the box as rendered with; -1 .. -39 scale its allowances by that power of two, -40 removes them.
+ * out[0] rays, out[1] rays left out, out[2] (ray, sphere) pairs checked for them, out[3] accepted roots over all pairs
+ * of all rays, out[4] accepted roots among the pairs of out[2]: must be 0. */
+RT_API int rt_selftest_box(rt_ctx *ctx, uint32_t seed, int blocks, int rays_per_thread, int padding_log2, uint64_t out[6]);
+
 /* No counterpart in the reference.  Host-only (no device, no context): the bounding balls the library builds at scene
  * upload for the kernels that prune candidates a group at a time, for `count` spheres given as (x, y, z, radius) in slot
  * order.  out receives RT_BOUND_FLOATS floats per word of 32 slots ((count + 31) / 32 words): (Cx, Cy, Cz, R2out),

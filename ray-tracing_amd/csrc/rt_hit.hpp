@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "rt_device.hpp"
 #include "rt_kernels.h"
 #include "rt_lift.hpp"
@@ -44,7 +46,10 @@ struct Rec4 { f4v r0, r1, r2, r3; };
 // kFetchTiled is the matrix-core filter for scenes beyond that: the spheres are partitioned in space into tiles of
 // at most 512, each lifted in a frame of its own; a workgroup streams the tiles through two LDS buffers
 // (asynchronous global -> LDS copies), all its waves working on the same tile between two barriers.
-enum { kFetchLds = 0, kFetchScalar = 1, kFetchStream = 2, kFetchMatrix = 3, kFetchTiled = 4 };
+// kFetchTiledDirect works on the same tiles where they lie in global memory: every wave first asks which tiles the rays
+// it holds can touch at all (a box per tile and per group of 16 tiles) and runs the filter for those tiles alone -- a
+// few of hundreds -- with its operands read straight from the L2 cache; no staging, no barriers, waves independent.
+enum { kFetchLds = 0, kFetchScalar = 1, kFetchStream = 2, kFetchMatrix = 3, kFetchTiled = 4, kFetchTiledDirect = 5 };
 constexpr int kTileRecords = 128;  // kFetchStream: records per LDS tile (two tiles per wave)
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -191,6 +196,17 @@ struct Fetch<kFetchTiled> {  // lifted tiles streamed through two LDS buffers pe
     static constexpr bool kTiled = true;
     static constexpr bool kScalarRecords = false;
     f4v *buf;            // LDS: two buffers of kTileVec4
+    const f4v *tiles;    // global
+    RT_DEV f4v load1(int k) const { return tiles[(size_t)(k / kTileSpheres) * kTileVec4 + kTileLifted + (k % kTileSpheres)]; }
+    RT_DEV int object_of(const TraceParams &P, int slot) const { return P.tile_obj[slot]; }
+    RT_DEV MatDev material(const TraceParams &P, int obj) const { return P.mats[obj]; }
+};
+
+template <>
+struct Fetch<kFetchTiledDirect> {  // the lifted tiles read in place (closest_sphere_direct)
+    static constexpr bool kMatrix = true;
+    static constexpr bool kTiled = true;
+    static constexpr bool kScalarRecords = false;
     const f4v *tiles;    // global
     RT_DEV f4v load1(int k) const { return tiles[(size_t)(k / kTileSpheres) * kTileVec4 + kTileLifted + (k % kTileSpheres)]; }
     RT_DEV int object_of(const TraceParams &P, int slot) const { return P.tile_obj[slot]; }
@@ -441,7 +457,7 @@ RT_DEV void lift_ray(const LiftFrame &F, V3 o, V3 dn, float slack, float &oo, Ra
 // tile-local relative slack at all.
 // oo returns |p|^2 for the range check; a ray whose constant term leaves the FP16 range reports oo = inf.
 constexpr float kNearSlack = 0x1p-18f;  // 64u
-RT_DEV void lift_ray_near(const LiftFrame &F, float cmax, V3 o, V3 dn, float slack, float near_slack, float &oo, RayLifted &L) {
+RT_DEV void lift_ray_near_slots(const LiftFrame &F, float cmax, V3 o, V3 dn, float slack, float near_slack, float &oo, h8 (&x)[4]) {
     const float fx = (o.x - F.tx) * F.sigma, fy = (o.y - F.ty) * F.sigma, fz = (o.z - F.tz) * F.sigma;
     const float far2 = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
     const float t0 = __builtin_fmaf(fz, dn.z, __builtin_fmaf(fy, dn.y, fx * dn.x));
@@ -458,7 +474,12 @@ RT_DEV void lift_ray_near(const LiftFrame &F, float cmax, V3 o, V3 dn, float sla
     v[4] = dn.x * dn.x; v[5] = dn.y * dn.y; v[6] = dn.z * dn.z;
     v[7] = dn.x * dn.y; v[8] = dn.x * dn.z; v[9] = dn.y * dn.z;
     oo = __builtin_fabsf(v[0]) <= 57000.0f ? pp : __builtin_inff();   // NaN compares false: inf
-    pack_lifted(v, L);
+    pack_lifted_slots(v, x);
+}
+RT_DEV void lift_ray_near(const LiftFrame &F, float cmax, V3 o, V3 dn, float slack, float near_slack, float &oo, RayLifted &L) {
+    h8 x[4];
+    lift_ray_near_slots(F, cmax, o, dn, slack, near_slack, oo, x);
+    exchange_lifted(x, L);
 }
 
 // Pass A on the matrix cores over 64-sphere blocks [blk0, blk1): same candidate words as filter_round.
@@ -559,7 +580,7 @@ RT_DEV uint32_t filter_round_matrix(const h8 *pm, int blk0, int blk1, uint32_t *
 // Conservativeness.  Whenever the reference's discriminant is >= 0 the ray's line passes within
 // sqrt(r^2 + 17u |o - c|^2) of the centre (closest_sphere), and the accepted root's point lies within the same
 // distance of it up to another 17u |o - c|^2 under the root; the host grows every sphere's radius to
-// sqrt(r^2 + 40u D^2) with D >= |o - c| for every origin this path admits (TraceParams::narrow_oo) before it takes the
+// sqrt(r^2 + 64u D^2) with D >= |o - c| for every origin this path admits (TraceParams::narrow_oo) before it takes the
 // box, and pads the box for the roundings of the test itself (rt_api.hip narrow_setup).  The test declares a miss only
 // on a separating axis of line and box (the three cross products of the direction with the box axes) or when the
 // origin lies outside a slab and the ray does not move towards it; every comparison is false on a NaN operand, so
@@ -601,19 +622,32 @@ RT_DEV void matrix_pair(const h8 a0_lo, const h8 a0_hi, const h8 a1_lo, const h8
 // Lane half h ends up with word 2 blk + h of its column's ray -- the rows a lane half receives are the spheres of one
 // word (lift_index) -- and writes it straight into the owner's place.  Returns the bitmap of the non-empty words this
 // lane wrote (the owner needs the OR over both halves of its column).
+// AHEAD: the sphere operands come from global memory; those of the next block are asked for before this block's matrix
+// instructions are issued.
+template <bool SPARSE = false, bool AHEAD = false>
 RT_DEV uint32_t filter_round_narrow(const h8 *pm, int blk0, int blk1, uint32_t *masks, int lane, const h8 b_lo, const h8 b_hi, int owner,
                                     bool column_used) {
     uint32_t nz = 0;
     const h8 *A = pm + (size_t)blk0 * 256 + lane;
     const int h = lane >> 5;
+    [[maybe_unused]] h8 n0, n1, n2, n3;
+    if constexpr (AHEAD) { n0 = A[0]; n1 = A[64]; n2 = A[128]; n3 = A[192]; }
     for (int blk = blk0, w = 0; blk < blk1; ++blk, w += 2, A += 256) {
         f32x16 q0, q1;
-        uint32_t word = 0;
-        matrix_pair(A[0], A[64], A[128], A[192], b_lo, b_hi, q0, q1);
+        uint32_t word = 0xFFFFFFFFu;
+        if constexpr (AHEAD) {
+            const h8 a0 = n0, a1 = n1, a2 = n2, a3 = n3;
+            if (blk + 1 < blk1) { n0 = A[256]; n1 = A[320]; n2 = A[384]; n3 = A[448]; }
+            matrix_pair(a0, a1, a2, a3, b_lo, b_hi, q0, q1);
+        } else {
+            matrix_pair(A[0], A[64], A[128], A[192], b_lo, b_hi, q0, q1);
+        }
+        if (!SPARSE || group_has_candidate(q0, q1)) {   // (see filter_round_matrix)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) word = push_sign(word, q0[k]);
+            for (int k = 0; k < 16; ++k) word = push_sign(word, q0[k]);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) word = push_sign(word, q1[k]);
+            for (int k = 0; k < 16; ++k) word = push_sign(word, q1[k]);
+        }
         const uint32_t c = ~word;
         if (column_used) masks[(w + h) * 64 + owner] = c;
         uint32_t b;
@@ -621,6 +655,53 @@ RT_DEV uint32_t filter_round_narrow(const h8 *pm, int blk0, int blk1, uint32_t *
         nz |= b << (w + h);
     }
     return column_used ? nz : 0u;
+}
+
+// The rays of the lanes in `touching` (at most 32) -> the columns of one ray tile, through the wave's candidate-word area,
+// which nothing uses at that time: a lane with such a ray writes its slot vectors to row `rank` (its number among those
+// lanes) and its lane number to the list; lanes l and l + 32 then read the K slots they supply for the ray of row l % 32
+// and that ray's lane.  never_unused: columns without a ray get operands that make every real sphere's q negative (for
+// the form of the filter that first asks whether a group has any candidate at all).
+RT_DEV void gather_columns(uint32_t *wave_masks, int lane, uint64_t touching, const h8 (&slots)[4], bool never_unused, h8 &b_lo, h8 &b_hi,
+                           int &owner) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 *rows = (u4 *)wave_masks;
+    uint32_t *list = wave_masks + kListOffset;
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(touching >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)touching, 0u));
+    if ((touching >> lane) & 1ull) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rows[rank * 4u + (uint32_t)i] = __builtin_bit_cast(u4, slots[i]);
+        list[rank] = (uint32_t)lane;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int col = lane & 31, half = lane >> 5;
+    b_lo = __builtin_bit_cast(h8, rows[col * 4 + half]);
+    b_hi = __builtin_bit_cast(h8, rows[col * 4 + 2 + half]);
+    owner = (int)list[col];
+    if (never_unused && col >= __builtin_popcountll(touching)) {
+        // slots 0 and 1 (x 1 on the sphere side) = -60000 each, slot 2 (x the leading part of -kq, at most 60000) = 1
+        const h8 never = {(_Float16)-60000.0f, (_Float16)-60000.0f, (_Float16)1.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+        const h8 zero = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+        b_lo = half == 0 ? never : zero;
+        b_hi = zero;
+    }
+    // (the words are written only after these reads have returned: LDS operations of a wave execute in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Non-empty-word bitmaps of filter_round_narrow -> the lanes the rays belong to.
+RT_DEV uint32_t scatter_bitmaps(uint32_t *wave_masks, int lane, uint64_t touching, uint32_t written) {
+    uint32_t *list = wave_masks + kListOffset;
+    list[lane] = written;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(touching >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)touching, 0u));
+    return (touching >> lane) & 1ull ? list[rank] | list[rank + 32u] : 0u;
 }
 
 // Pass B for slots that are in object order, balanced over the wave.  Lanes differ in how many candidates pass A left
@@ -1388,9 +1469,7 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
     best[lane] = ((unsigned long long)__float_as_uint(tbest) << 32) | 0xFFFFFFFFull;
     f.start(general);
     // Matrix kind: the filter at half width when at most 32 rays of the wave can touch the box of the scene's small
-    // spheres (filter_round_narrow).  The rays that can are moved into one ray tile through the (still unused)
-    // candidate-word area: a lane with such a ray writes its slot vectors to row `rank` (its number among those lanes)
-    // and its lane number to the list; lanes l and l + 32 then read the K slots they supply for the ray of row l % 32.
+    // spheres (filter_round_narrow); those rays are moved into one ray tile (gather_columns).
     uint64_t touching = 0;
     bool narrow = false;
     int owner = lane;
@@ -1401,28 +1480,7 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
             const int n = __builtin_popcountll(touching);
             narrow = n <= 32;
             work.wide_waves = narrow ? 0u : work.wide_waves + 1u;
-            if (narrow) {
-                typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-                u4 *rows = (u4 *)wave_masks;
-                uint32_t *list = wave_masks + kListOffset;
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(touching >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)touching, 0u));
-                if (touch) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) rows[rank * 4u + (uint32_t)i] = __builtin_bit_cast(u4, slots[i]);
-                    list[rank] = (uint32_t)lane;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int col = lane & 31, half = lane >> 5;
-                lifted.b00 = __builtin_bit_cast(h8, rows[col * 4 + half]);
-                lifted.b01 = __builtin_bit_cast(h8, rows[col * 4 + 2 + half]);
-                owner = (int)list[col];
-                // (the words are written only after these reads have returned: LDS operations of a wave execute in order)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
+            if (narrow) gather_columns(wave_masks, lane, touching, slots, false, lifted.b00, lifted.b01, owner);
         } else if (P.narrow != 0 && !general) {
             // a wave most of whose rays touch the box stops asking for a while
             work.wide_waves = (work.wide_waves + 1u) & 31u;
@@ -1443,14 +1501,9 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
             if (narrow) {
                 nz = 0;
                 if (touching != 0) {
-                    const int n = __builtin_popcountll(touching);
-                    uint32_t *list = wave_masks + kListOffset;
-                    list[lane] = filter_round_narrow(f.pm, blk0, blk1, wave_masks, lane, lifted.b00, lifted.b01, owner, (lane & 31) < n);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(touching >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)touching, 0u));
-                    if ((touching >> lane) & 1ull) nz = list[rank] | list[rank + 32u];
+                    const uint32_t written = filter_round_narrow(f.pm, blk0, blk1, wave_masks, lane, lifted.b00, lifted.b01, owner,
+                                                                 (lane & 31) < __builtin_popcountll(touching));
+                    nz = scatter_bitmaps(wave_masks, lane, touching, written);
                     work.blocks += (uint32_t)(blk1 - blk0);
                 }
                 // the spheres the box does not stand for, every lane for its own ray
@@ -1459,6 +1512,9 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
                     const int w = (int)P.wide_word[k] - g0 / kWordGroups;
                     if (w < 0 || w >= kRoundWords) continue;
                     uint32_t m = (nz >> w) & 1u ? wave_masks[w * 64 + lane] : 0u;
+                    // (Leaving a sphere no filter can hold -- the cover scene's ground -- out for rays that start outside it and
+                    // lead away, b = oc.d > 0 and c = |oc|^2 - r^2 > 0 in the reference's own arithmetic, was measured: half of
+                    // the rays qualify, and the twelve instructions cost 0.8 % more than the exact pass saves.)
                     m |= P.wide_always[k];
                     for (uint32_t t = P.wide_test[k]; t != 0; t &= t - 1) {
                         const int j = 31 - __builtin_ctz(t);  // bit 31 - j is slot 32 w + j
@@ -1564,9 +1620,9 @@ RT_DEV int closest_sphere_tiled(const TraceParams &P, Fetch<kFetchTiled> &f, uin
         // this wave copied right after the barrier: wait for the copy explicitly.
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0), expcnt and lgkmcnt untouched
         __syncthreads();
-        if (t + 1 < P.ntiles) tile_copy(P, f, t + 1, (t + 1) & 1, (int)frames[2 * t + 3].y);
+        if (t + 1 < P.ntiles) tile_copy(P, f, t + 1, (t + 1) & 1, (int)frames[kTileFrameVec4 * (t + 1) + 1].y);
         const f4v *tile = f.buf + (t & 1) * kTileVec4;
-        const f4v fa = frames[2 * t], fb = frames[2 * t + 1];
+        const f4v fa = frames[kTileFrameVec4 * t], fb = frames[kTileFrameVec4 * t + 1];
         const LiftFrame F = {fa.x, fa.y, fa.z, fa.w};
         const int count = (int)fb.y;
         float oo;
@@ -1627,6 +1683,121 @@ RT_DEV int closest_sphere_tiled(const TraceParams &P, Fetch<kFetchTiled> &f, uin
     return ibest;
 }
 
+// closest_sphere for the tiled kind that reads its tiles in place.  The tiles are those of closest_sphere_tiled (spatial
+// order, lifted in a frame of their own, ties in distance to the lower object index); what differs is who looks at
+// which tile.  Most rays miss most tiles of a large scene: a ray can have a candidate in a tile only if it can touch the
+// box around the tile's spheres, and a wave looks at a tile only if one of the rays it holds can -- first asked of
+// groups of 16 consecutive tiles (consecutive tiles are neighbours in space: they are the leaves of the median splits in
+// order), then of the tiles of the groups that are left.  For a tile it does look at, the rays that touch it (up to 32;
+// beyond that the filter runs at full width) are gathered into one ray tile and the filter runs at half width
+// (filter_round_narrow), its sphere operands read from global memory -- that is, from the L2 cache, which holds the
+// whole scene: 196 tiles of 40 KB for 100 000 spheres.  Nothing is staged and no wave waits for another.
+//
+// The box test (ray_may_touch_box; see filter_round_narrow for why a ray that fails it has no candidate): here the
+// origin may be any distance from the tile, so the allowances are taken per ray from D = |o - mid| + half diagonal,
+// which bounds |o - c| for every centre c in the box: a sphere's radius grows to sqrt(r^2 + 64u D^2) <= r + 2^-9 D,
+// the test's own roundings are within 2^-16 D, and the host has widened the half extents by 1 + 2^-12.  A tile (or
+// group) with a sphere that no box can stand for has infinite half extents.
+template <bool PROF>
+RT_DEV int closest_sphere_direct(const TraceParams &P, Fetch<kFetchTiledDirect> &f, uint32_t *wave_masks, bool active, V3 o, V3 d,
+                                 float &tbest, Prof<PROF> &prof, Work &work) {
+    const float a = dot(d, d);
+    const bool a_ok = !(__builtin_fabsf(a) < 1e-6f);  // Lib.metal:226-228
+    const RootDiv dv = root_div(a, active);
+    const float s = __builtin_amdgcn_rsqf(a) * kDirScale;
+    const V3 dn = v3(d.x * s, d.y * s, d.z * s);
+    const int lane = threadIdx.x & 63;
+    int ibest = -1;
+    float nskip = __builtin_inff();
+    const const_f4_ptr frames = (const_f4_ptr)(uintptr_t)P.tile_frames;
+    const const_f4_ptr groups = frames + kTileFrameVec4 * P.ntiles;
+    auto touches = [&](f4v bm, f4v bh) -> bool {
+        const float ex = o.x - bm.x, ey = o.y - bm.y, ez = o.z - bm.z;
+        const float dist = __builtin_sqrtf(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex))) * (1.0f + 0x1p-20f) + bm.w;
+        const float pad = dist * (0x1p-9f * (1.0f + 0x1p-6f) + 0x1p-16f);
+        return active && a_ok && ray_may_touch_box(o, d, v3(bm.x, bm.y, bm.z), v3(bh.x + pad, bh.y + pad, bh.z + pad));
+    };
+    if (__builtin_amdgcn_ballot_w64(active && a_ok) == 0) return -1;
+    for (int t0 = 0; t0 < P.ntiles; t0 += kTileGroup) {
+        if (__builtin_amdgcn_ballot_w64(touches(groups[2 * (t0 / kTileGroup)], groups[2 * (t0 / kTileGroup) + 1])) == 0) continue;
+        const int t1 = min(P.ntiles, t0 + kTileGroup);
+        for (int t = t0; t < t1; ++t) {
+            const bool touch = touches(frames[kTileFrameVec4 * t + 2], frames[kTileFrameVec4 * t + 3]);
+            const uint64_t touching = __builtin_amdgcn_ballot_w64(touch);
+            if (touching == 0) continue;
+            const f4v fa = frames[kTileFrameVec4 * t], fb = frames[kTileFrameVec4 * t + 1];
+            const f4v *tile = f.tiles + (size_t)t * kTileVec4;
+            const LiftFrame F = {fa.x, fa.y, fa.z, fa.w};
+            const int count = (int)fb.y;
+            float oo;
+            h8 slots[4];
+            lift_ray_near_slots(F, fb.z, o, dn, kMfmaSlack, kNearSlack, oo, slots);
+            const bool general = __builtin_amdgcn_ballot_w64(touch && !(oo <= fb.x)) != 0;  // wave-uniform
+            uint32_t nz;
+            if (general) {
+                RayGeneral y = {o, dn};
+                TileStrict ts = {tile + kTileLifted};
+                nz = filter_round(ts, 0, (count + 3) / 4, count, wave_masks, lane, y);
+            } else {
+                __builtin_amdgcn_s_setprio(0);
+                const int nblk = (count + 63) / 64;
+                const int n = __builtin_popcountll(touching);
+                if (n <= 32) {
+                    h8 b_lo, b_hi;
+                    int owner;
+                    gather_columns(wave_masks, lane, touching, slots, true, b_lo, b_hi, owner);
+                    const uint32_t written = filter_round_narrow<true, true>((const h8 *)tile, 0, nblk, wave_masks, lane, b_lo, b_hi, owner, (lane & 31) < n);
+                    nz = scatter_bitmaps(wave_masks, lane, touching, written);
+                    work.blocks += (uint32_t)nblk;
+                } else {
+                    RayLifted lifted;
+                    exchange_lifted(slots, lifted);
+                    nz = filter_round_matrix<true>((const h8 *)tile, 0, nblk, wave_masks, lane, lifted);
+                    work.blocks += 2u * (uint32_t)nblk;
+                }
+                __builtin_amdgcn_s_setprio(1);
+            }
+            if (!touch) nz = 0;
+            prof.lap(1);
+            uint32_t m = 0;
+            int w = 0;
+            for (;;) {
+                if (m == 0) {
+                    if (nz == 0) break;
+                    w = __builtin_ctz(nz);
+                    nz &= nz - 1;
+                    m = wave_masks[w * 64 + lane];
+                }
+                const int j = __builtin_clz(m);
+                m &= ~(0x80000000u >> j);
+                if constexpr (PROF) {
+                    prof.count(6);
+                    prof.count(7, (uint64_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)));
+                }
+                const int kl = w * 32 + j;
+                // Lib.metal:216-238 as written
+                f4v rec = tile[kTileLifted + kl];  // (center, radius)
+                float ocx = o.x - rec.x, ocy = o.y - rec.y, ocz = o.z - rec.z;
+                float b = ocx * d.x + ocy * d.y + ocz * d.z;
+                float c = (ocx * ocx + ocy * ocy + ocz * ocz) - rec.w * rec.w;
+                float disc = b * b - a * c;
+                float root, n;
+                bool tie;
+                if (sphere_root_any_order(disc, b, dv, tbest, nskip, n, root, tie)) {
+                    const int k = t * kTileSpheres + kl;
+                    if (!tie || (ibest >= 0 && P.tile_obj[k] < P.tile_obj[ibest])) {
+                        tbest = root;
+                        ibest = k;
+                        nskip = n * (1.0f + 0x1p-22f);
+                    }
+                }
+            }
+            prof.lap(2);
+        }
+    }
+    return ibest;
+}
+
 // Closest hit over spheres and quads; fills hit and returns the object index or -1.
 template <typename F, bool PROF, bool DENSE = false>
 RT_DEV int world_hit(const TraceParams &P, F &f, uint32_t *wave_masks, bool active, V3 o, V3 d, Hit &hit, float &t_out,
@@ -1634,7 +1805,9 @@ RT_DEV int world_hit(const TraceParams &P, F &f, uint32_t *wave_masks, bool acti
     float tbest = kMaxFloat;
     int slot;
     ++work.trips;
-    if constexpr (F::kTiled) {
+    if constexpr (std::is_same_v<F, Fetch<kFetchTiledDirect>>) {
+        slot = closest_sphere_direct(P, f, wave_masks, active, o, d, tbest, prof, work);
+    } else if constexpr (F::kTiled) {
         slot = closest_sphere_tiled(P, f, wave_masks, active, o, d, tbest, prof, work);
     } else {
         slot = closest_sphere<F, PROF, DENSE>(P, f, wave_masks, active, o, d, tbest, prof, work);
@@ -1730,6 +1903,8 @@ RT_DEV void stage_scene(const TraceParams &P, uint32_t *lds_words, uint32_t *&wa
         f.pmat = P.stage_mats ? mt : nullptr;
     } else if constexpr (KIND == kFetchTiled) {
         f.buf = (f4v *)after_masks;
+        f.tiles = (const f4v *)P.tiles;
+    } else if constexpr (KIND == kFetchTiledDirect) {
         f.tiles = (const f4v *)P.tiles;
     } else if constexpr (KIND == kFetchScalar) {
         f.pc = (const_f4_ptr)(uintptr_t)P.sphc;

@@ -18,6 +18,8 @@ constexpr int kQueueRays = 64;  // camera rays per lane in the trace kernel's pe
 constexpr int kTileSpheres = 512;                      // sphere slots per tile = one resolve round
 constexpr int kTileLifted = kTileSpheres * 4;          // float4 of lifted A operands per tile (64 bytes per sphere)
 constexpr int kTileVec4 = kTileLifted + kTileSpheres;  // ... followed by the strict records
+constexpr int kTileFrameVec4 = 4;                      // float4 per tile in TraceParams::tile_frames
+constexpr int kTileGroup = 16;                         // consecutive tiles that share a box of their own (rt_hit.hpp closest_sphere_direct)
 
 // Everything one trace launch needs.  Passed by value in the kernel argument segment.  The first block is
 // read on every trip of the kernel's main loop and lives in scalar registers; the kernel reads the second
@@ -43,7 +45,10 @@ struct TraceParams {
                             // together), 2048 float4 of lifted A operands in the tile's own frame, then the 512
                             // strict records
     const float4 *tile_frames;  // per tile (tx, ty, tz, sigma), (range limit in the tile's frame, spheres,
-                                // largest |c'| of a filtered sphere, 0)
+                                // largest |c'| of a filtered sphere, 0), (centre of the box around the tile's spheres,
+                                // length of its half diagonal), (its half extents x (1 + 2^-12), 0); a tile with a sphere
+                                // no box can stand for: infinite half extents.  After the tiles: the same two float4 (box
+                                // centre and half diagonal, half extents) for every group of kTileGroup consecutive tiles
     const int *tile_obj;    // [ntiles * 512] object index of each slot in tile order (-1: padding)
     int ntiles;
     int stage_mats;         // matrix-core kind: sph_obj and mats are staged in LDS too (the launch reserved the room)
@@ -137,6 +142,9 @@ hipError_t launch_matrix_selftest(uint32_t seed, int blocks, int rounds, float s
 // sph: nsph strict records (x, y, z, radius) in slot order; bounds: their bounding balls (TraceParams::word_bounds)
 hipError_t launch_prune_selftest(uint32_t seed, int blocks, int rays_per_thread, const float4 *sph, const float4 *bounds, int nsph,
                                  unsigned long long *out, hipStream_t stream);
+// the box of the half-width filter (P.narrow_oo, cull_mid, cull_half, wide_*, lift) against the exact hit test of every sphere
+hipError_t launch_box_selftest(uint32_t seed, int blocks, int rays_per_thread, const float4 *sph, int nsph, const TraceParams &P,
+                               unsigned long long *out, hipStream_t stream);
 hipError_t launch_fold(float4 *accum, const float4 *planes, int nplanes, int width, int height, int tileX, int tileY,
                        int tileW, int tileH, hipStream_t stream);
 // The reference's per-pixel epilogue for one pass over a tile (Shaders.metal:142-160) on tile-sized planes that hold one

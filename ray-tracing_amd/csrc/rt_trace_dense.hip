@@ -10,7 +10,7 @@ namespace rt {
 
 template <int KIND>
 static const void *pick(bool profile, bool single) {
-    constexpr bool kHasDense = KIND != kFetchTiled;  // the tiled kind keeps its slots in spatial order: no pruning form
+    constexpr bool kHasDense = !Fetch<KIND>::kTiled;  // the tiled kinds keep their slots in spatial order: no pruning form
     if (profile) return (const void *)trace_kernel<KIND, true, false, kHasDense>;
     if constexpr (kHasDense) {
         return single ? (const void *)trace_kernel<KIND, false, true, true> : (const void *)trace_kernel<KIND, false, false, true>;
@@ -25,6 +25,7 @@ const void *trace_kernel_dense(int fetch_kind, bool profile, bool single) {
         case kFetchStream: return pick<kFetchStream>(profile, single);
         case kFetchMatrix: return pick<kFetchMatrix>(profile, single);
         case kFetchTiled: return pick<kFetchTiled>(profile, single);
+        case kFetchTiledDirect: return pick<kFetchTiledDirect>(profile, single);
     }
     return nullptr;
 }

@@ -26,6 +26,7 @@ def strict(r, rt, chunk=0, fetch=0):
     r.set_option(rt.RT_OPT_TAIL_SAMPLES, -1)
     r.set_option(rt.RT_OPT_BLOCKS_PER_CU, 0)
     r.set_option(rt.RT_OPT_RESOLVE, 0)
+    r.set_option(rt.RT_OPT_NARROW, 1)
 
 
 def test_committed_images_bit_exact(rt, renderer):
@@ -85,12 +86,14 @@ def test_images_bit_exact(rt, oracle, renderer, name, w, h, spp, depth):
     assert np.array_equal(bits(img), bits(want))
 
 
-@pytest.mark.parametrize("fetch,path", [(0, 4), (1, 1), (2, 2)])
-def test_scene_larger_than_lds_bit_exact(rt, oracle, renderer, fetch, path):
-    """5000 spheres exceed the LDS staging limit: by default the workgroups stream lifted tiles through LDS (matrix-core
-    filter, spheres visited in spatial order); on request the records come through the scalar cache or per-wave tiles
-    (vector filter, object order).  All give the oracle's bits."""
+@pytest.mark.parametrize("fetch,narrow,path", [(0, 1, 5), (0, 0, 4), (1, 1, 1), (2, 1, 2)])
+def test_scene_larger_than_lds_bit_exact(rt, oracle, renderer, fetch, narrow, path):
+    """5000 spheres exceed the LDS staging limit: by default every wave reads the lifted tiles its rays can touch in place
+    (matrix-core filter at half width, spheres visited in spatial order); with RT_OPT_NARROW 0 the workgroups stream all
+    tiles through LDS; on request the records come through the scalar cache or per-wave tiles (vector filter, object
+    order).  All give the oracle's bits."""
     strict(renderer, rt, fetch=fetch)
+    renderer.set_option(rt.RT_OPT_NARROW, narrow)
     objs, n = rt.scene("random_spheres", n=5000, extent=20.0)
     u = rt.config_uniforms("random_spheres", 96, 54, 2, 50, n)
     renderer.setupTexture(96, 54)
@@ -130,19 +133,21 @@ def test_tiled_matrix_filter_awkward_spheres_bit_exact(rt, oracle, renderer):
     u = rt.config_uniforms("random_spheres", w, h, spp, 50, n)
     renderer.setupTexture(w, h)
     want = oracle.image(u, objs, w, h)
-    for fetch, path in ((0, 4), (3, 4), (1, 1)):
+    for fetch, narrow, path in ((0, 1, 5), (3, 1, 5), (0, 0, 4), (3, 0, 4), (1, 1, 1)):
         strict(renderer, rt, fetch=fetch)
+        renderer.set_option(rt.RT_OPT_NARROW, narrow)
         try:
             img = renderer.renderImage(u, objs, n)
             assert renderer.lastStats().scene_path == path
         finally:
             strict(renderer, rt)
-        assert np.array_equal(bits(img), bits(want)), fetch
+        assert np.array_equal(bits(img), bits(want)), (fetch, narrow)
 
 
 def test_tiled_and_vector_filters_agree_on_100k_spheres(rt, renderer):
-    """The 100 000-sphere configuration at 640x360 x 4 spp, beyond what the oracle checks in seconds: streamed lifted
-    tiles (default) against the vector filter through the scalar cache, bit for bit, and run-to-run determinism."""
+    """The 100 000-sphere configuration at 640x360 x 4 spp, beyond what the oracle checks in seconds: lifted tiles read
+    in place (default, twice: run-to-run determinism) and streamed through LDS against the vector filter through the
+    scalar cache, bit for bit."""
     strict(renderer, rt, chunk=2)
     w, h, spp = 640, 360, 4
     objs, n = rt.scene("random_spheres")
@@ -150,8 +155,9 @@ def test_tiled_and_vector_filters_agree_on_100k_spheres(rt, renderer):
     renderer.setupTexture(w, h)
     renderer.setScene(objs, n)
     imgs = []
-    for fetch, path in ((0, 4), (0, 4), (1, 1)):
+    for fetch, narrow, path in ((0, 1, 5), (0, 1, 5), (1, 1, 1), (0, 0, 4)):
         strict(renderer, rt, chunk=2, fetch=fetch)
+        renderer.set_option(rt.RT_OPT_NARROW, narrow)
         try:
             renderer.accumClear()
             renderer.render(u, None, 0, 0, spp)
@@ -162,6 +168,7 @@ def test_tiled_and_vector_filters_agree_on_100k_spheres(rt, renderer):
             strict(renderer, rt)
     assert np.array_equal(bits(imgs[0]), bits(imgs[1]))
     assert np.array_equal(bits(imgs[0]), bits(imgs[2]))
+    assert np.array_equal(bits(imgs[0]), bits(imgs[3]))
 
 
 def test_chunked_work_items_sum_in_chunk_order(rt, oracle, renderer):
@@ -427,10 +434,12 @@ def oracle_spot_pixels(oracle, u, objs, pixels, ranges, workers=8):
 
 def test_100k_sphere_configuration_spot_pixels(rt, oracle, renderer):
     """The 100 000-sphere configuration at its own size -- 1920x1080, 64 spp, depth 50, default options (lifted tiles
-    streamed through LDS, matrix-core filter, spheres visited in spatial order) -- at 24 scattered pixels against the
+    read in place by the waves whose rays can touch them, matrix-core filter at half width, spheres visited in spatial
+    order) -- at 24 scattered pixels against the
     oracle's brute-force loop over all objects (Shaders.metal:13-32), bit for bit."""
     for opt in (rt.RT_OPT_SCENE_FETCH, rt.RT_OPT_FILTER, rt.RT_OPT_BLOCKS_PER_CU):
         renderer.set_option(opt, 0)
+    renderer.set_option(rt.RT_OPT_NARROW, 1)
     for opt in (rt.RT_OPT_CHUNK, rt.RT_OPT_TAIL_CHUNK, rt.RT_OPT_TAIL_SAMPLES):
         renderer.set_option(opt, -1)
     w, h, spp = 1920, 1080, 64
@@ -444,7 +453,7 @@ def test_100k_sphere_configuration_spot_pixels(rt, oracle, renderer):
     renderer.resolve(spp)
     img = renderer.readTexture()
     st = renderer.lastStats()
-    assert st.scene_path == 4 and st.samples == w * h * spp and st.tests == st.segments * n
+    assert st.scene_path == 5 and st.samples == w * h * spp and st.tests == st.segments * n
     ranges = st.chunk_ranges(0, spp)
     assert ranges[0][0] == 0 and ranges[-1][1] == spp and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
     rng = np.random.RandomState(5)
@@ -958,13 +967,16 @@ def test_random_scenes_matrix_equals_vector(rt, renderer, seed, extent, offset):
             assert path == 3
     assert np.array_equal(bits(imgs[3]), bits(imgs[2]))
     assert len(np.unique(bits(imgs[3]).reshape(-1, 4), axis=0)) > 50   # the camera really sees the spheres
-    renderer.set_option(rt.RT_OPT_SCENE_FETCH, 3)   # the same scene as one lifted tile in its own frame
+    renderer.set_option(rt.RT_OPT_SCENE_FETCH, 3)   # the same scene as one lifted tile in its own frame, read in place or staged
     try:
-        tiled = renderer.renderImage(u, arr, nsph)
-        assert renderer.lastStats().scene_path == 4
+        for narrow, path in ((1, 5), (0, 4)):
+            renderer.set_option(rt.RT_OPT_NARROW, narrow)
+            tiled = renderer.renderImage(u, arr, nsph)
+            assert renderer.lastStats().scene_path == path
+            assert np.array_equal(bits(tiled), bits(imgs[2])), narrow
     finally:
         renderer.set_option(rt.RT_OPT_SCENE_FETCH, 0)
-    assert np.array_equal(bits(tiled), bits(imgs[2]))
+        renderer.set_option(rt.RT_OPT_NARROW, 1)
 
 
 def _layer_scene(rt, case):
@@ -1073,6 +1085,30 @@ def test_half_width_filter_at_scale(rt, renderer):
     assert np.array_equal(bits(imgs[0]), bits(imgs[1]))
     assert np.array_equal(bits(imgs[0]), bits(imgs[2]))
     assert per_trip[0] < 0.6 * per_trip[1] and per_trip[1] == 8.0, per_trip
+
+
+@pytest.mark.parametrize("kind", ["cover", "cover_like", "wide_in_the_middle", "two_rounds", "thick_cloud"])
+def test_box_test_leaves_out_no_ray_the_reference_would_hit_with(rt, renderer, kind):
+    """rt_selftest_box on the scene's own spheres and box: rays from on or next to sphere surfaces and box faces, tangent,
+    aimed at silhouettes or running along a face.  No ray the box test leaves out may have an accepted root on a sphere
+    the box stands for -- with the padding the library renders with, and with a quarter of it."""
+    if kind == "cover":
+        arr, n = rt.scene(kind)
+    else:
+        objs = _layer_scene(rt, kind)[0]
+        n = len(objs)
+        arr = rt.object_array(objs)
+    renderer.setScene(arr, n)
+    for padding in (0, -2):
+        tot = {"rays": 0, "left_out": 0, "pairs": 0, "roots": 0}
+        for seed in (1, 2, 3):
+            r = renderer.selftestBox(seed=seed, blocks=512, rays_per_thread=4, padding_log2=padding)
+            assert r["wrong"] == 0, (padding, r)
+            for k in tot:
+                tot[k] += r[k]
+        assert tot["rays"] > 1e6 and tot["roots"] > tot["rays"]        # the rays do hit spheres ...
+        assert tot["left_out"] > 0.1 * tot["rays"], tot                # ... and the test is not vacuous
+        assert tot["pairs"] > 100 * tot["left_out"]
 
 
 def test_default_path_of_the_cover_scene_is_the_matrix_filter(rt, renderer):

@@ -11,7 +11,7 @@ r = rt.MetalRenderer(0)
 cases = [("three_spheres", {}, 400, 225, 100, 50), ("cover", {}, 1200, 675, 500, 50), ("cover", {}, 1920, 1080, 1000, 50),
          ("cover", {}, 3840, 2160, 1000, 50), ("nested_glass", {}, 1920, 1080, 64, 100),
          ("random_spheres", {}, 1920, 1080, 64, 50), ("cornell", {}, 800, 600, 256, 30)]
-paths = {0: "vector, LDS-staged", 1: "vector, scalar cache", 2: "vector, streamed", 3: "matrix cores, staged", 4: "matrix cores, streamed tiles"}
+paths = {0: "vector, LDS-staged", 1: "vector, scalar cache", 2: "vector, streamed", 3: "matrix cores, staged", 4: "matrix cores, streamed tiles", 5: "matrix cores, tiles in place"}
 for name, kw, w, h, spp, depth in cases:
     objs, n = rt.scene(name, **kw)
     r.setupTexture(w, h)
