@@ -263,6 +263,13 @@ RT_API int rt_selftest_prune(rt_ctx *ctx, uint32_t seed, int blocks, int rays_pe
  * of all rays, out[4] accepted roots among the pairs of out[2]: must be 0. */
 RT_API int rt_selftest_box(rt_ctx *ctx, uint32_t seed, int blocks, int rays_per_thread, int padding_log2, uint64_t out[6]);
 
+/* No counterpart in the reference.  The same for the boxes of the tiled kind that reads its tiles in place (scenes beyond
+ * 1024 spheres, or RT_OPT_SCENE_FETCH 3): a ray that the box of a tile, or of its group of 64 tiles, leaves out must have
+ * no accepted root on any sphere of that tile.  Origins on, near or up to 2^12 radii away from a sphere, or on a face of
+ * a tile's box.  padding_log2 scales the allowances that grow with the ray's distance (0: as rendered with; -40: none).
+ * out as rt_selftest_box, out[1] counting (ray, tile) pairs left out. */
+RT_API int rt_selftest_tile_boxes(rt_ctx *ctx, uint32_t seed, int blocks, int rays_per_thread, int padding_log2, uint64_t out[6]);
+
 /* No counterpart in the reference.  Host-only (no device, no context): the bounding balls the library builds at scene
  * upload for the kernels that prune candidates a group at a time, for `count` spheres given as (x, y, z, radius) in slot
  * order.  out receives RT_BOUND_FLOATS floats per word of 32 slots ((count + 31) / 32 words): (Cx, Cy, Cz, R2out),

@@ -109,7 +109,7 @@ AMD_SYMBOLS = [
     "rt_write_target", "rt_read_target", "rt_render_tile", "rt_present_bgra8", "rt_set_scene", "rt_render",
     "rt_render_noalloc",
     "rt_accum_clear", "rt_accum_ptr", "rt_resolve", "rt_synchronize", "rt_first_hit", "rt_last_stats", "rt_trace_times",
-    "rt_selftest_filter", "rt_selftest_matrix_filter", "rt_selftest_tiled_filter", "rt_selftest_prune", "rt_selftest_box", "rt_group_bounds",
+    "rt_selftest_filter", "rt_selftest_matrix_filter", "rt_selftest_tiled_filter", "rt_selftest_prune", "rt_selftest_box", "rt_selftest_tile_boxes", "rt_group_bounds",
 ]
 HOST_SYMBOLS = [
     "rt_material_default", "rt_material_lambertian", "rt_material_metal", "rt_material_dielectric", "rt_material_light",
@@ -157,6 +157,7 @@ def amd_lib():
         lib.rt_selftest_tiled_filter.argtypes = [vp, C.c_uint32, ip, ip, ip, vp]
         lib.rt_selftest_prune.argtypes = [vp, C.c_uint32, ip, ip, vp]
         lib.rt_selftest_box.argtypes = [vp, C.c_uint32, ip, ip, ip, vp]
+        lib.rt_selftest_tile_boxes.argtypes = [vp, C.c_uint32, ip, ip, ip, vp]
         lib.rt_group_bounds.argtypes = [vp, ip, vp]
         _amd = lib
     return _amd
@@ -506,6 +507,12 @@ class MetalRenderer:
         """On the scene set with setScene."""
         out = (C.c_uint64 * 6)()
         self._check(self._lib.rt_selftest_box(self._ctx, seed, blocks, rays_per_thread, padding_log2, out))
+        return dict(zip(["rays", "left_out", "pairs", "roots", "wrong"], list(out)))
+
+    def selftestTileBoxes(self, seed=1, blocks=256, rays_per_thread=2, padding_log2=0):
+        """On the scene set with setScene."""
+        out = (C.c_uint64 * 6)()
+        self._check(self._lib.rt_selftest_tile_boxes(self._ctx, seed, blocks, rays_per_thread, padding_log2, out))
         return dict(zip(["rays", "left_out", "pairs", "roots", "wrong"], list(out)))
 
     def selftestTiledFilter(self, seed=1, blocks=1024, rounds=64, slack_log2=-16):

@@ -1678,6 +1678,27 @@ RT_API int rt_selftest_box(rt_ctx *ctx, uint32_t seed, int blocks, int rays_per_
     return RT_OK;
 }
 
+RT_API int rt_selftest_tile_boxes(rt_ctx *ctx, uint32_t seed, int blocks, int rays_per_thread, int padding_log2, uint64_t out[6]) {
+    if (!ctx || !out || blocks <= 0 || rays_per_thread <= 0 || padding_log2 > 0 || padding_log2 < -40) return RT_ERR_INVALID;
+    if (!ctx->scene_resident || ctx->nsph <= 0 || ctx->ntiles <= 0)
+        return fail(ctx, RT_ERR_NO_SCENE, "rt_selftest_tile_boxes: set a scene with spheres first (rt_set_scene)");
+    Bind bind(ctx);
+    TraceParams P;
+    Uniforms u;
+    std::memset(&u, 0, sizeof u);
+    fill_params(ctx, &u, P);
+    RT_TRY(grow(ctx, ctx->staging, 256));
+    unsigned long long *dev = (unsigned long long *)ctx->staging.ptr;
+    hipError_t e = hipMemsetAsync(dev, 0, 256, ctx->stream);
+    if (e == hipSuccess) e = launch_tile_box_selftest(seed, blocks, rays_per_thread, P, padding_log2 <= -40 ? 0.0f : std::ldexp(1.0f, padding_log2), dev, ctx->stream);
+    unsigned long long host[6] = {0, 0, 0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(host, dev, sizeof host, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_selftest_tile_boxes", e);
+    for (int i = 0; i < 6; ++i) out[i] = host[i];
+    return RT_OK;
+}
+
 static int selftest_matrix(rt_ctx *ctx, uint32_t seed, int blocks, int rounds, int slack_log2, int far, uint64_t out[6]) {
     if (!ctx || !out || blocks <= 0 || rounds <= 0 || slack_log2 > -8 || slack_log2 < -30) return RT_ERR_INVALID;
     Bind bind(ctx);

@@ -20,11 +20,16 @@ constexpr int kRoundWords = 16;   // candidate words per resolve round (512 sphe
 constexpr int kListOffset = kRoundWords * 64;        // after a wave's candidate words: 64 words of candidate list ...
 constexpr int kBestOffset = kListOffset + 64;        // ... and 64 x 64 bits of (distance, slot) minima (resolve_balanced)
 constexpr int kMaskWordsPerWave = kBestOffset + 128; // LDS words per wave
+#ifndef RT_FEW_RAYS
+#define RT_FEW_RAYS 8
+#endif
 #ifndef RT_REST_POOLED
 #define RT_REST_POOLED 64
 #endif
 constexpr int kRestPooled = RT_REST_POOLED;  // dense rounds: candidates in the whole wave after the prune up to which the pooled form resolves them
 constexpr int kRestPerLane = 12;   // dense rounds: candidates per lane after the prune up to which every lane resolves its own
+constexpr int kFewRays = RT_FEW_RAYS;  // tiled kind read in place: rays of a wave that touch a tile up to which every lane tests eight of the tile's spheres
+                                       // exactly for one ray after the other (closest_sphere_direct); more go through the matrix-core filter
 constexpr int kDenseWordBits = 8;  // candidates in a word of 32 spheres from which the word counts as dense (closest_sphere)
 
 // Filter margins (see closest_sphere).  kDirScale inflates the b side of both filters; the c side is inflated
@@ -47,7 +52,7 @@ struct Rec4 { f4v r0, r1, r2, r3; };
 // at most 512, each lifted in a frame of its own; a workgroup streams the tiles through two LDS buffers
 // (asynchronous global -> LDS copies), all its waves working on the same tile between two barriers.
 // kFetchTiledDirect works on the same tiles where they lie in global memory: every wave first asks which tiles the rays
-// it holds can touch at all (a box per tile and per group of 16 tiles) and runs the filter for those tiles alone -- a
+// it holds can touch at all (a box per tile and per group of 64 tiles) and runs the filter for those tiles alone -- a
 // few of hundreds -- with its operands read straight from the L2 cache; no staging, no barriers, waves independent.
 enum { kFetchLds = 0, kFetchScalar = 1, kFetchStream = 2, kFetchMatrix = 3, kFetchTiled = 4, kFetchTiledDirect = 5 };
 constexpr int kTileRecords = 128;  // kFetchStream: records per LDS tile (two tiles per wave)
@@ -599,6 +604,17 @@ RT_DEV bool ray_may_touch_box(V3 o, V3 d, V3 m, V3 h) {
     miss = miss || (__builtin_fabsf(ey) > h.y && ey * d.y >= 0.0f);
     miss = miss || (__builtin_fabsf(ez) > h.z && ez * d.z >= 0.0f);
     return !miss;
+}
+
+// The same for a box the ray may start any distance from (the tiled kinds): bm = (centre, length of the half diagonal),
+// bh = half extents, already widened by 1 + 2^-12 on the host.  The allowances are taken per ray from
+// D = |o - centre| + half diagonal, which bounds |o - c| for every sphere centre c in the box: a radius grows to
+// sqrt(r^2 + 64u D^2) <= r + 2^-9 D, and the test's own roundings are within 2^-16 D.  scale (self-test only) scales both.
+RT_DEV bool ray_may_touch_far_box(V3 o, V3 d, f4v bm, f4v bh, float scale = 1.0f) {
+    const float ex = o.x - bm.x, ey = o.y - bm.y, ez = o.z - bm.z;
+    const float dist = __builtin_sqrtf(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex))) * (1.0f + 0x1p-20f) + bm.w;
+    const float pad = dist * ((0x1p-9f * (1.0f + 0x1p-6f) + 0x1p-16f) * scale);
+    return ray_may_touch_box(o, d, v3(bm.x, bm.y, bm.z), v3(bh.x + pad, bh.y + pad, bh.z + pad));
 }
 
 // Two 32-sphere groups against one ray tile: q0 = group 0, q1 = group 1 (fenced and read like matrix_group).
@@ -1686,18 +1702,17 @@ RT_DEV int closest_sphere_tiled(const TraceParams &P, Fetch<kFetchTiled> &f, uin
 // closest_sphere for the tiled kind that reads its tiles in place.  The tiles are those of closest_sphere_tiled (spatial
 // order, lifted in a frame of their own, ties in distance to the lower object index); what differs is who looks at
 // which tile.  Most rays miss most tiles of a large scene: a ray can have a candidate in a tile only if it can touch the
-// box around the tile's spheres, and a wave looks at a tile only if one of the rays it holds can -- first asked of
-// groups of 16 consecutive tiles (consecutive tiles are neighbours in space: they are the leaves of the median splits in
-// order), then of the tiles of the groups that are left.  For a tile it does look at, the rays that touch it (up to 32;
-// beyond that the filter runs at full width) are gathered into one ray tile and the filter runs at half width
-// (filter_round_narrow), its sphere operands read from global memory -- that is, from the L2 cache, which holds the
-// whole scene: 196 tiles of 40 KB for 100 000 spheres.  Nothing is staged and no wave waits for another.
-//
-// The box test (ray_may_touch_box; see filter_round_narrow for why a ray that fails it has no candidate): here the
-// origin may be any distance from the tile, so the allowances are taken per ray from D = |o - mid| + half diagonal,
-// which bounds |o - c| for every centre c in the box: a sphere's radius grows to sqrt(r^2 + 64u D^2) <= r + 2^-9 D,
-// the test's own roundings are within 2^-16 D, and the host has widened the half extents by 1 + 2^-12.  A tile (or
-// group) with a sphere that no box can stand for has infinite half extents.
+// box around the tile's spheres (ray_may_touch_far_box; see filter_round_narrow for why a ray that fails it has no
+// candidate in the box; a tile or group with a sphere that no box can stand for has infinite half extents).  Per group
+// of 64 consecutive tiles (consecutive tiles are neighbours in space: they are the leaves of the median splits in order):
+//   every lane asks whether its own ray can touch the group's box;
+//   lane j takes the box of the group's tile j and is asked about those rays one after the other (or, in a group of
+//   fewer tiles than rays, every lane is asked about its own ray, tile after tile);
+//   the wave then visits the tiles some ray touches.  For up to kFewRays rays every lane tests eight of the tile's
+//   slots exactly, ray after ray; more rays (up to 32) are gathered into one ray tile and the matrix-core filter runs
+//   at half width (filter_round_narrow), beyond that at full width, its sphere operands read from global memory --
+//   from the L2 and Infinity caches, which hold the whole scene: 196 tiles of 40 KB for 100 000 spheres.
+// Nothing is staged and no wave waits for another.
 template <bool PROF>
 RT_DEV int closest_sphere_direct(const TraceParams &P, Fetch<kFetchTiledDirect> &f, uint32_t *wave_masks, bool active, V3 o, V3 d,
                                  float &tbest, Prof<PROF> &prof, Work &work) {
@@ -1707,26 +1722,111 @@ RT_DEV int closest_sphere_direct(const TraceParams &P, Fetch<kFetchTiledDirect> 
     const float s = __builtin_amdgcn_rsqf(a) * kDirScale;
     const V3 dn = v3(d.x * s, d.y * s, d.z * s);
     const int lane = threadIdx.x & 63;
-    int ibest = -1;
+    int ibest = -1, obest = 0;   // slot in tile order and object index of the best hit so far
     float nskip = __builtin_inff();
     const const_f4_ptr frames = (const_f4_ptr)(uintptr_t)P.tile_frames;
     const const_f4_ptr groups = frames + kTileFrameVec4 * P.ntiles;
-    auto touches = [&](f4v bm, f4v bh) -> bool {
-        const float ex = o.x - bm.x, ey = o.y - bm.y, ez = o.z - bm.z;
-        const float dist = __builtin_sqrtf(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex))) * (1.0f + 0x1p-20f) + bm.w;
-        const float pad = dist * (0x1p-9f * (1.0f + 0x1p-6f) + 0x1p-16f);
-        return active && a_ok && ray_may_touch_box(o, d, v3(bm.x, bm.y, bm.z), v3(bh.x + pad, bh.y + pad, bh.z + pad));
-    };
-    if (__builtin_amdgcn_ballot_w64(active && a_ok) == 0) return -1;
+    const bool live = active && a_ok;
+    if (__builtin_amdgcn_ballot_w64(live) == 0) return -1;
+    auto bcast = [](float v, int l) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
     for (int t0 = 0; t0 < P.ntiles; t0 += kTileGroup) {
-        if (__builtin_amdgcn_ballot_w64(touches(groups[2 * (t0 / kTileGroup)], groups[2 * (t0 / kTileGroup) + 1])) == 0) continue;
-        const int t1 = min(P.ntiles, t0 + kTileGroup);
-        for (int t = t0; t < t1; ++t) {
-            const bool touch = touches(frames[kTileFrameVec4 * t + 2], frames[kTileFrameVec4 * t + 3]);
-            const uint64_t touching = __builtin_amdgcn_ballot_w64(touch);
-            if (touching == 0) continue;
+        // the rays that can touch the group's box at all, every lane asking for its own ray
+        const uint64_t rays = __builtin_amdgcn_ballot_w64(live && ray_may_touch_far_box(o, d, groups[2 * (t0 / kTileGroup)], groups[2 * (t0 / kTileGroup) + 1]));
+        if (rays == 0) continue;
+        // which of the group's 64 tiles each of those rays can touch: lane j holds the box of tile t0 + j and is asked about
+        // one ray after the other (the ray's numbers broadcast from its lane); it keeps the set of rays that touch its tile
+        const int tj = t0 + lane;
+        const bool real = tj < P.ntiles;
+        const f4v *fr = (const f4v *)P.tile_frames + kTileFrameVec4 * (real ? tj : t0);
+        const f4v bm = fr[2], bh = fr[3];
+        uint32_t set_lo = 0, set_hi = 0;
+        const int ngroup = min(kTileGroup, P.ntiles - t0);
+        if (__builtin_popcountll(rays) < ngroup) {
+            for (uint64_t rest = rays; rest != 0; rest &= rest - 1) {
+                const int L = __builtin_amdgcn_readfirstlane(__builtin_ctzll(rest));
+                const V3 ro = v3(bcast(o.x, L), bcast(o.y, L), bcast(o.z, L)), rd = v3(bcast(d.x, L), bcast(d.y, L), bcast(d.z, L));
+                if (real && ray_may_touch_far_box(ro, rd, bm, bh)) {
+                    set_lo |= L < 32 ? 1u << L : 0u;
+                    set_hi |= L < 32 ? 0u : 1u << (L - 32);
+                }
+            }
+        } else {
+            // fewer tiles than rays: the other way round, every lane asking about its own ray, tile after tile
+            for (int j = 0; j < ngroup; ++j) {
+                const uint64_t hit = __builtin_amdgcn_ballot_w64(((rays >> lane) & 1ull) && ray_may_touch_far_box(o, d, frames[kTileFrameVec4 * (t0 + j) + 2], frames[kTileFrameVec4 * (t0 + j) + 3]));
+                if (lane == j) {
+                    set_lo = (uint32_t)hit;
+                    set_hi = (uint32_t)(hit >> 32);
+                }
+            }
+        }
+        for (uint64_t tiles = __builtin_amdgcn_ballot_w64((set_lo | set_hi) != 0u); tiles != 0; tiles &= tiles - 1) {
+            const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(tiles));
+            const int t = t0 + j;
+            const uint64_t touching = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)set_hi, j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)set_lo, j);
+            const bool touch = (touching >> lane) & 1ull;
             const f4v fa = frames[kTileFrameVec4 * t], fb = frames[kTileFrameVec4 * t + 1];
             const f4v *tile = f.tiles + (size_t)t * kTileVec4;
+            const int n = __builtin_popcountll(touching);
+            if (n <= kFewRays && P.nobj <= (1 << 23)) {
+                // A few rays against the tile's 512 slots: no filter at all.  Every lane holds the strict records of eight
+                // slots (eight coalesced loads, all in flight at once) and evaluates the reference's own discriminant
+                // (Lib.metal:216-224, the same operations in the same order) for one ray after the other, the ray's
+                // numbers broadcast from its lane; a lane that finds an accepted root offers (root, object, slot) to the
+                // ray's 64-bit minimum in LDS, root in the upper half -- positive floats order like unsigned integers,
+                // so the minimum is the smallest root and, among equal roots, the lowest object index, which is the
+                // reference's choice (Shaders.metal:17-22; see resolve_balanced for why the root a sphere offers does
+                // not depend on the best so far).
+                f4v rec[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) rec[i] = tile[kTileLifted + 64 * i + lane];
+                unsigned long long *offer = (unsigned long long *)(wave_masks + kBestOffset);
+                if (touch) offer[lane] = ~0ull;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (uint64_t rest = touching; rest != 0; rest &= rest - 1) {
+                    const int L = __builtin_amdgcn_readfirstlane(__builtin_ctzll(rest));
+                    const V3 ro = v3(bcast(o.x, L), bcast(o.y, L), bcast(o.z, L)), rd = v3(bcast(d.x, L), bcast(d.y, L), bcast(d.z, L));
+                    RootDiv q;
+                    q.a = bcast(dv.a, L);
+                    q.r = bcast(dv.r, L);
+                    q.nmin = q.a * 0.0009f;
+                    q.slow = dv.slow;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float ocx = ro.x - rec[i].x, ocy = ro.y - rec[i].y, ocz = ro.z - rec[i].z;
+                        const float b = ocx * rd.x + ocy * rd.y + ocz * rd.z;
+                        const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - rec[i].w * rec[i].w;
+                        const float disc = b * b - q.a * c;
+                        if (disc >= 0.0f) {
+                            float root, nbest = __builtin_inff();
+                            if (sphere_root(disc, b, q, kMaxFloat, nbest, root)) {
+                                const uint32_t kl = (uint32_t)(64 * i + lane);
+                                const uint32_t obj = (uint32_t)P.tile_obj[t * kTileSpheres + (int)kl];
+                                atomicMin(&offer[L], ((unsigned long long)__float_as_uint(root) << 32) | (obj << 9) | kl);
+                            }
+                        }
+                    }
+                    if constexpr (PROF) prof.count(7, 512);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (touch) {
+                    const unsigned long long key = offer[lane];
+                    const float root = __uint_as_float((uint32_t)(key >> 32));
+                    const int obj = (int)((uint32_t)key >> 9);
+                    if (key != ~0ull && (root < tbest || (root == tbest && ibest >= 0 && obj < obest))) {
+                        tbest = root;
+                        ibest = t * kTileSpheres + (int)((uint32_t)key & 511u);
+                        obest = obj;
+                        nskip = __builtin_inff();  // (the numerator did not travel: no division is skipped on its account)
+                    }
+                }
+                prof.lap(2);
+                continue;
+            }
             const LiftFrame F = {fa.x, fa.y, fa.z, fa.w};
             const int count = (int)fb.y;
             float oo;
@@ -1741,7 +1841,6 @@ RT_DEV int closest_sphere_direct(const TraceParams &P, Fetch<kFetchTiledDirect> 
             } else {
                 __builtin_amdgcn_s_setprio(0);
                 const int nblk = (count + 63) / 64;
-                const int n = __builtin_popcountll(touching);
                 if (n <= 32) {
                     h8 b_lo, b_hi;
                     int owner;
@@ -1785,9 +1884,11 @@ RT_DEV int closest_sphere_direct(const TraceParams &P, Fetch<kFetchTiledDirect> 
                 bool tie;
                 if (sphere_root_any_order(disc, b, dv, tbest, nskip, n, root, tie)) {
                     const int k = t * kTileSpheres + kl;
-                    if (!tie || (ibest >= 0 && P.tile_obj[k] < P.tile_obj[ibest])) {
+                    const int obj = P.tile_obj[k];
+                    if (!tie || (ibest >= 0 && obj < obest)) {
                         tbest = root;
                         ibest = k;
+                        obest = obj;
                         nskip = n * (1.0f + 0x1p-22f);
                     }
                 }

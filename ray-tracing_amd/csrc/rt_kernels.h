@@ -19,7 +19,7 @@ constexpr int kTileSpheres = 512;                      // sphere slots per tile 
 constexpr int kTileLifted = kTileSpheres * 4;          // float4 of lifted A operands per tile (64 bytes per sphere)
 constexpr int kTileVec4 = kTileLifted + kTileSpheres;  // ... followed by the strict records
 constexpr int kTileFrameVec4 = 4;                      // float4 per tile in TraceParams::tile_frames
-constexpr int kTileGroup = 16;                         // consecutive tiles that share a box of their own (rt_hit.hpp closest_sphere_direct)
+constexpr int kTileGroup = 64;                         // consecutive tiles that share a box of their own (rt_hit.hpp closest_sphere_direct)
 
 // Everything one trace launch needs.  Passed by value in the kernel argument segment.  The first block is
 // read on every trip of the kernel's main loop and lives in scalar registers; the kernel reads the second
@@ -145,6 +145,9 @@ hipError_t launch_prune_selftest(uint32_t seed, int blocks, int rays_per_thread,
 // the box of the half-width filter (P.narrow_oo, cull_mid, cull_half, wide_*, lift) against the exact hit test of every sphere
 hipError_t launch_box_selftest(uint32_t seed, int blocks, int rays_per_thread, const float4 *sph, int nsph, const TraceParams &P,
                                unsigned long long *out, hipStream_t stream);
+// the boxes of the tiles and tile groups (P.tiles, P.tile_frames, P.ntiles), their allowances scaled by `scale`
+hipError_t launch_tile_box_selftest(uint32_t seed, int blocks, int rays_per_thread, const TraceParams &P, float scale,
+                                    unsigned long long *out, hipStream_t stream);
 hipError_t launch_fold(float4 *accum, const float4 *planes, int nplanes, int width, int height, int tileX, int tileY,
                        int tileW, int tileH, hipStream_t stream);
 // The reference's per-pixel epilogue for one pass over a tile (Shaders.metal:142-160) on tile-sized planes that hold one

@@ -41,8 +41,11 @@ struct RegroupLds {
 
 // BUILD: nothing in the kernel depends on it; it keeps apart instantiations that two translation units compile with
 // different flags (same template arguments would make them one symbol, and one of the two builds would be dropped).
+#ifndef RT_DIRECT_WAVES
+#define RT_DIRECT_WAVES 4
+#endif
 template <int KIND, bool PROF, bool SINGLE = false, bool DENSE = false, bool REGROUP = false, int BUILD = 0>
-__global__ __launch_bounds__(KIND == kFetchMatrix || KIND == kFetchTiled ? 1024 : 256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+__global__ __launch_bounds__(KIND == kFetchMatrix || KIND == kFetchTiled ? 1024 : 256) __attribute__((amdgpu_waves_per_eu(KIND == kFetchTiledDirect ? RT_DIRECT_WAVES : 4, 8)))
 void trace_kernel(const TraceParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_words[];
     uint32_t *wave_masks;

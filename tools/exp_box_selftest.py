@@ -27,4 +27,14 @@ for kind in ("cover", "cover_like", "wide_in_the_middle", "two_rounds", "thick_c
                 tot[k] = tot.get(k, 0) + v
         print("%-20s padding 2^%-3d rays %.3g left out %.3g pairs %.3g roots %.3g wrong %d" %
               (kind, padding, tot["rays"], tot["left_out"], tot["pairs"], tot["roots"], tot["wrong"]), flush=True)
+for n, extent in ((5000, 20.0), (20000, 22.0), (100000, None)):
+    arr, n = rt.scene("random_spheres", n=n, extent=extent) if extent else rt.scene("random_spheres")
+    r.setScene(arr, n)
+    for padding in (0, -3, -6, -10, -40):
+        tot = {}
+        for seed in range(1, seeds + 1):
+            for k, v in r.selftestTileBoxes(seed=seed, blocks=max(1, blocks // (8 if n < 50000 else 64)), rays_per_thread=2, padding_log2=padding).items():
+                tot[k] = tot.get(k, 0) + v
+        print("tiles of %6d spheres padding 2^%-3d rays %.3g (ray, tile) left out %.3g pairs %.3g roots %.3g wrong %d" %
+              (n, padding, tot["rays"], tot["left_out"], tot["pairs"], tot["roots"], tot["wrong"]), flush=True)
 r.close()
