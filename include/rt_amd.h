@@ -63,8 +63,11 @@ enum {
                                1 = through the scalar cache into scalar registers (vector filter),
                                2 = streamed from global memory through per-wave LDS tiles (vector filter),
                                3 = spheres sorted in space and cut into tiles of 512, each lifted in a frame of its
-                                   own; every workgroup streams the tiles through two LDS buffers and runs the
-                                   matrix-core filter on them (any scene size) */
+                                   own (any scene size).  With RT_OPT_NARROW 1 (default) the tiles are read where they
+                                   lie: a wave visits only the tiles its rays can touch (a box per tile and per 64
+                                   tiles), tests a few rays per tile exactly and runs the matrix-core filter for more;
+                                   with RT_OPT_NARROW 0 every workgroup streams all tiles through two LDS buffers and
+                                   runs the matrix-core filter on them */
     RT_OPT_BLOCKS_PER_CU = 5, /* persistent grid size = this x compute units; 0 = occupancy query */
     RT_OPT_FILTER = 6,      /* which conservative sphere filter precedes the exact hit test; results are identical:
                                0 = automatic (default): the matrix-core filter for LDS-staged scenes of 48 to 1024
@@ -100,10 +103,11 @@ enum {
                                them (short paths) goes back to an item per lane.  Results are identical.  Measured: one
                                rank's share of the benchmark frame at 8 ranks +0.4 %, nested shells +1.3 %, Cornell box -4 %,
                                hence not the default */
-    RT_OPT_NARROW = 14,     /* staged matrix-core kind: 1 (default) = where at most 32 rays of a wave can touch the box around the
-                               scene's ordinary spheres, the sphere filter runs on those rays alone, at half width (scenes of 128
-                               spheres or more with at most 8 spheres much larger than the rest); 0 = always at full width.
-                               Results are identical */
+    RT_OPT_NARROW = 14,     /* 1 (default) = rays that cannot touch the box around a group of spheres are left out of its sphere
+                               filter.  Staged matrix-core kind (scenes of 128 spheres or more with at most 8 spheres much
+                               larger than the rest): where at most 32 rays of a wave can touch the box around the ordinary
+                               spheres, the filter runs on those rays alone, at half width.  Tiled kind: see
+                               RT_OPT_SCENE_FETCH 3.  0 = every ray against every sphere.  Results are identical */
     RT_OPT_REGROUP = 11     /* material scatter of the staged matrix kind's batch kernels (results are identical):
                                0 = automatic (default), 1 = every lane scatters its own path, 2 = requests are sorted by
                                material over the workgroup through LDS, so that a wave runs one branch of the material
@@ -201,7 +205,8 @@ struct rt_stats {
     int block_threads;
     int scene_path;  /* how the last trace launch read and filtered the spheres: 0 staged in LDS + vector filter,
                         1 scalar cache + vector filter, 2 streamed + vector filter, 3 staged in LDS + matrix-core filter,
-                        4 lifted tiles streamed through LDS + matrix-core filter */
+                        4 lifted tiles streamed through LDS + matrix-core filter, 5 lifted tiles read in place by the
+                        waves whose rays can touch them */
     /* Work items of the last rt_render launch: the sample indices of a pixel were cut into chunk_count chunks of
      * chunk samples followed by chunks of tail_chunk samples (the last one shorter if need be).  Each chunk is
      * summed sample by sample, and the chunk sums are added in order. */

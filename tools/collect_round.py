@@ -77,4 +77,7 @@ with open(prefix + "_phase_profile.txt", "w") as o:
 text("progressive.txt", prefix + "_progressive_tiles.txt", "tools/exp_progressive.py: the reference's tile flow, one blocking rt_render_tile per 64x64 tile")
 text("prune_selftest.txt", prefix + "_prune_selftest.txt", "tools/exp_prune_selftest.py 4 2048 8")
 text("rank_share.txt", prefix + "_rank_share.txt", "tools/exp_rank_share.py: one rank's share of the benchmark frame; last number of a label: 0 = lanes share planes before the counter runs out, 1 = only after")
+text("narrow.txt", prefix + "_narrow.txt", "tools/exp_narrow.py: the staged matrix kind with its sphere filter at half width for the rays that can touch the box of the scene's small spheres (RT_OPT_NARROW 1) against full width (0)")
+text("narrow_tiled.txt", prefix + "_narrow_tiled.txt", "tools/exp_narrow_tiled.py: tiles read in place by the waves whose rays can touch them (RT_OPT_NARROW 1, path 5) against all tiles streamed through LDS (0, path 4)")
+text("box_selftest.txt", prefix + "_box_selftest.txt", "tools/exp_box_selftest.py 4 2048 8: rays the box tests leave out against the exact hit test, with the library's padding (2^0) and with less")
 print("collected under", prefix, "kernel source id", kid)

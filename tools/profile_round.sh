@@ -24,4 +24,7 @@ run progressive 200 python3 tools/exp_progressive.py
 run prune_selftest 400 python3 tools/exp_prune_selftest.py 4 2048 8
 run rank_share 400 python3 tools/exp_rank_share.py -1,-1,-1,-1,0 -1,-1,-1,-1,1
 run persistent_nested_small 200 env SCENE=nested_glass DEPTH=100 SIZE=1200x675 python3 tools/exp_libs.py 16 1 ray-tracing_amd/lib/librt_amd.so
+run narrow 300 python3 tools/exp_narrow.py
+run narrow_tiled 400 python3 tools/exp_narrow_tiled.py 2000 5000 20000 100000
+run box_selftest 600 python3 tools/exp_box_selftest.py 4 2048 8
 echo "== done ($(date +%T))"
