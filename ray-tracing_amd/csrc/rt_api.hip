@@ -968,7 +968,7 @@ void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
     P.fine_plane0 = 0;
     P.share_begin = 0xFFFFFFFFu;
     P.regroup = ctx->opt_regroup == 2 && ctx->opt_kernel != 1 ? 1 : 0;
-    P.narrow = ctx->narrow.ok && ctx->opt_narrow != 0 ? 1 : 0;
+    P.narrow = ctx->narrow.ok && ctx->opt_narrow != 0 ? 1 : 0;  // (cleared below for the kernels that do without: P.dense_kernel)
     P.narrow_oo = ctx->narrow.oo;
     P.cull_mid = ctx->narrow.mid;
     P.cull_half = ctx->narrow.half;
@@ -979,6 +979,7 @@ void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
         P.wide_always[k] = ctx->narrow.always[k];
     }
     P.dense_kernel = ctx->opt_resolve == 2 || (ctx->opt_resolve == 0 && ctx->scene_dense) ? 1 : 0;
+    if (P.dense_kernel) P.narrow = 0;
     P.width = ctx->width;
     P.height = ctx->height;
     P.pass = u->currentSample;

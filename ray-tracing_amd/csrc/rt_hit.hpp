@@ -1489,7 +1489,10 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
     uint64_t touching = 0;
     bool narrow = false;
     int owner = lane;
-    if constexpr (F::kMatrix) {
+    // (not in the kernels for scenes whose rays cross many spheres, which have no registers to spare for it: the host never
+    // sets P.narrow for them; the stamped instantiation, which stands in for both, carries it)
+    constexpr bool kNarrow = F::kMatrix && (!DENSE || PROF);
+    if constexpr (kNarrow) {
         if (P.narrow != 0 && !general && work.wide_waves < 4u) {
             const bool touch = active && a_ok && (!(oo <= P.narrow_oo) || ray_may_touch_box(o, d, P.cull_mid, P.cull_half));
             touching = __builtin_amdgcn_ballot_w64(touch);
@@ -1502,6 +1505,8 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
             work.wide_waves = (work.wide_waves + 1u) & 31u;
         }
         if (!narrow) exchange_lifted(slots, lifted);
+    } else if constexpr (F::kMatrix) {
+        exchange_lifted(slots, lifted);
     }
     for (int g0 = 0; g0 < P.ngroups; g0 += kRoundWords * kWordGroups) {
         const int g1 = min(P.ngroups, g0 + kRoundWords * kWordGroups);
@@ -1514,7 +1519,7 @@ RT_DEV int closest_sphere(const TraceParams &P, F &f, uint32_t *wave_masks, bool
             // chains: a wave outside the filter goes first when it has an instruction ready (+2.8 % measured).
             __builtin_amdgcn_s_setprio(0);
             const int blk0 = g0 / 16, blk1 = (g1 + 15) / 16;
-            if (narrow) {
+            if (kNarrow && narrow) {
                 nz = 0;
                 if (touching != 0) {
                     const uint32_t written = filter_round_narrow(f.pm, blk0, blk1, wave_masks, lane, lifted.b00, lifted.b01, owner,
