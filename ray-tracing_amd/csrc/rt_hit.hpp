@@ -674,8 +674,8 @@ RT_DEV uint32_t filter_round_narrow(const h8 *pm, int blk0, int blk1, uint32_t *
 }
 
 // The rays of the lanes in `touching` (at most 32) -> the columns of one ray tile, through the wave's candidate-word area,
-// which nothing uses at that time: a lane with such a ray writes its slot vectors to row `rank` (its number among those
-// lanes) and its lane number to the list; lanes l and l + 32 then read the K slots they supply for the ray of row l % 32
+// which nothing uses at that time: a lane with such a ray writes its four slot octets to row `rank` (its number among those
+// lanes) of four arrays and its lane number to the list; lanes l and l + 32 then read the K slots they supply for the ray of row l % 32
 // and that ray's lane.  never_unused: columns without a ray get operands that make every real sphere's q negative (for
 // the form of the filter that first asks whether a group has any candidate at all).
 RT_DEV void gather_columns(uint32_t *wave_masks, int lane, uint64_t touching, const h8 (&slots)[4], bool never_unused, h8 &b_lo, h8 &b_hi,
@@ -686,15 +686,15 @@ RT_DEV void gather_columns(uint32_t *wave_masks, int lane, uint64_t touching, co
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(touching >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)touching, 0u));
     if ((touching >> lane) & 1ull) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rows[rank * 4u + (uint32_t)i] = __builtin_bit_cast(u4, slots[i]);
+        for (int i = 0; i < 4; ++i) rows[(uint32_t)i * 32u + rank] = __builtin_bit_cast(u4, slots[i]);   // [slot octet][row]: no bank conflicts
         list[rank] = (uint32_t)lane;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int col = lane & 31, half = lane >> 5;
-    b_lo = __builtin_bit_cast(h8, rows[col * 4 + half]);
-    b_hi = __builtin_bit_cast(h8, rows[col * 4 + 2 + half]);
+    b_lo = __builtin_bit_cast(h8, rows[half * 32 + col]);
+    b_hi = __builtin_bit_cast(h8, rows[(2 + half) * 32 + col]);
     owner = (int)list[col];
     if (never_unused && col >= __builtin_popcountll(touching)) {
         // slots 0 and 1 (x 1 on the sphere side) = -60000 each, slot 2 (x the leading part of -kq, at most 60000) = 1

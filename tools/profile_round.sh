@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything the tables under profiles/ and in DESIGN.md are made from, in one call on the GPU box:
+# Everything the tables under profiles/ are made from, in one call on the GPU box:
 #   tools/profile_round.sh <outdir>          (then: tools/collect_round.py <outdir> profiles/r0N)
 # Every step runs under its own time limit and the script stops at the first failure.
 set -u
