@@ -274,10 +274,15 @@ def main():
                 "traffic_source": traffic_src,
                 "kernel": "trace_kernel (rank 0)",
                 "note": "achieved = executed FP16 matrix flops of the conservative sphere filter (kernel-counted 64x64 "
-                        "blocks x 8 instructions x 32768 flop) / launch time, against the dense FP16 matrix peak; the "
-                        "kernel is bound by SIMD issue shared between matrix and vector instructions, so the rest of "
-                        "the time is vector work (sign extraction, exact hit tests, shading)",
+                        "blocks x 8 instructions x 32768 flop, a block at half width counting as half) / launch time, "
+                        "against the dense FP16 matrix peak; the kernel is bound by SIMD issue shared between matrix and "
+                        "vector instructions, so the rest of the time is vector work (sign extraction, exact hit tests, "
+                        "shading).  Rays that cannot touch the box of the spheres the filter stands for are not put "
+                        "through it (RT_OPT_NARROW): executed matrix work per closest-hit search is matrix_blocks_per_search "
+                        "of the scene's blocks_per_search_at_full_width, so frac falls where value rises",
                 "mfma_flops_per_launch": mfma_flops,
+                "matrix_blocks_per_search": st.matrix_blocks / max(1, st.wave_trips),
+                "blocks_per_search_at_full_width": (st.tests // max(1, st.segments) + 63) // 64 if st.scene_path == 3 else None,
             }
         else:
             roofline = {

@@ -27,4 +27,5 @@ run persistent_nested_small 200 env SCENE=nested_glass DEPTH=100 SIZE=1200x675 p
 run narrow 300 python3 tools/exp_narrow.py
 run narrow_tiled 400 python3 tools/exp_narrow_tiled.py 2000 5000 20000 100000
 run box_selftest 600 python3 tools/exp_box_selftest.py 4 2048 8
+run tile_box_margin 600 python3 tools/exp_tile_box_margin.py
 echo "== done ($(date +%T))"
