@@ -15,7 +15,11 @@ constexpr int kWideWords = 4;  // words of 32 sphere slots that may hold spheres
 constexpr int kQueueRays = 64;  // camera rays per lane in the trace kernel's per-wave queue (two float4 each)
 
 // Tiled matrix-core kind (TraceParams::tiles, rt_hit.hpp closest_sphere_tiled).
-constexpr int kTileSpheres = 512;                      // sphere slots per tile = one resolve round
+#ifndef RT_TILE_SPHERES
+#define RT_TILE_SPHERES 512
+#endif
+constexpr int kTileSpheres = RT_TILE_SPHERES;          // sphere slots per tile (a power of two from 64 to 512: at most one resolve round)
+static_assert(kTileSpheres >= 64 && kTileSpheres <= 512 && (kTileSpheres & (kTileSpheres - 1)) == 0, "tile size");
 constexpr int kTileLifted = kTileSpheres * 4;          // float4 of lifted A operands per tile (64 bytes per sphere)
 constexpr int kTileVec4 = kTileLifted + kTileSpheres;  // ... followed by the strict records
 constexpr int kTileFrameVec4 = 4;                      // float4 per tile in TraceParams::tile_frames
