@@ -258,6 +258,17 @@ RT_API int rt_selftest_tiled_filter(rt_ctx *ctx, uint32_t seed, int blocks, int 
  * root the reference computes is not above the ray's bound: both must be 0. */
 RT_API int rt_selftest_prune(rt_ctx *ctx, uint32_t seed, int blocks, int rays_per_thread, uint64_t out[6]);
 
+/* No counterpart in the reference.  Host-only (no device, no context): the box the library would build at scene upload
+ * for the half-width sphere filter (RT_OPT_NARROW) of `count` spheres given as (x, y, z, radius) in slot order.  Returns
+ * 1 and fills out when the scene gets one, 0 when it does without (fewer than 128 spheres, more than 8 spheres outside
+ * the box or in more than 4 words of 32 slots, or a scene the lifted form does not cover).  out[0..2] the box's centre,
+ * out[3..5] its half extents (allowances included), out[6] the distance from the scene's median centre up to which the
+ * box test speaks for a ray's origin, out[7] the number of words that hold spheres outside the box, then per such word
+ * three 32-bit patterns stored in the floats' bytes: the word's index (slot / 32), the spheres tested for every ray with
+ * the vector filter, the spheres that are candidates for every ray (bit 31 - j for slot 32 w + j). */
+#define RT_FILTER_BOX_FLOATS 20
+RT_API int rt_filter_box(const float *spheres_xyzr, int count, float out[RT_FILTER_BOX_FLOATS]);
+
 /* No counterpart in the reference.  Self-test of the box test that lets rays skip the matrix-core sphere filter
  * (RT_OPT_NARROW), on the scene set with rt_set_scene (RT_ERR_INVALID when the scene has no such box): blocks x 256
  * threads build rays_per_thread rays each -- origins on or a few ulps off a sphere's surface or a face of the box,

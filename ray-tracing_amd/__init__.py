@@ -109,7 +109,7 @@ AMD_SYMBOLS = [
     "rt_write_target", "rt_read_target", "rt_render_tile", "rt_present_bgra8", "rt_set_scene", "rt_render",
     "rt_render_noalloc",
     "rt_accum_clear", "rt_accum_ptr", "rt_resolve", "rt_synchronize", "rt_first_hit", "rt_last_stats", "rt_trace_times",
-    "rt_selftest_filter", "rt_selftest_matrix_filter", "rt_selftest_tiled_filter", "rt_selftest_prune", "rt_selftest_box", "rt_selftest_tile_boxes", "rt_group_bounds",
+    "rt_selftest_filter", "rt_selftest_matrix_filter", "rt_selftest_tiled_filter", "rt_selftest_prune", "rt_selftest_box", "rt_selftest_tile_boxes", "rt_group_bounds", "rt_filter_box",
 ]
 HOST_SYMBOLS = [
     "rt_material_default", "rt_material_lambertian", "rt_material_metal", "rt_material_dielectric", "rt_material_light",
@@ -295,6 +295,25 @@ def group_bounds(spheres):
     if n < 0:
         raise RtError(n, "rt_group_bounds")
     return out[:n]
+
+
+def filter_box(spheres):
+    """The box of the half-width sphere filter as the library builds it at scene upload (host only).  spheres: (n, 4)
+    float32 (x, y, z, radius).  Returns None when the scene does without, else a dict: mid, half (3 floats each), reach,
+    and words = [(word index, tested bits, always bits), ...]."""
+    import numpy as np
+    sph = np.ascontiguousarray(spheres, dtype=np.float32).reshape(-1, 4)
+    out = np.zeros(20, np.float32)
+    lib = amd_lib()
+    lib.rt_filter_box.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    r = lib.rt_filter_box(sph.ctypes.data, len(sph), out.ctypes.data)
+    if r < 0:
+        raise RtError(r, "rt_filter_box")
+    if r == 0:
+        return None
+    bits = out.view(np.uint32)
+    return {"mid": out[0:3].copy(), "half": out[3:6].copy(), "reach": float(out[6]),
+            "words": [(int(bits[8 + 3 * k]), int(bits[9 + 3 * k]), int(bits[10 + 3 * k])) for k in range(int(out[7]))]}
 
 
 def generate_tiles(width, height, tileSize=64):

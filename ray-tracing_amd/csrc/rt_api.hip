@@ -338,6 +338,80 @@ NarrowSet narrow_setup(const std::vector<float4> &sph, int nsph, const std::vect
     return N;
 }
 
+// Matrix-core filter (rt_lift.hpp) of the staged kind: frame = median centre and a power-of-two scale that puts the 95th
+// percentile of |c - T|_inf + r near 42 (of the 244 that the FP16 range allows for a ray origin), lifted
+// records in A-operand order, and the origin limit: the hard range limit, or less when 10 % of the spheres
+// would see their filter radius^2 doubled by the slack.
+struct LiftSet {
+    std::vector<_Float16> sphm;
+    LiftFrame frame = {0.0f, 0.0f, 0.0f, 1.0f};
+    float oo_limit_m = -1.0f;
+    int outliers = 0;
+    std::vector<char> lifted_ok;  // per sphere: the lifted form holds it (else it is a candidate for every ray)
+};
+LiftSet lift_setup(const std::vector<float4> &sph, int nsph) {
+    LiftSet L;
+    std::vector<_Float16> &sphm = L.sphm;
+    LiftFrame &frame = L.frame;
+    float &oo_limit_m = L.oo_limit_m;
+    int &outliers = L.outliers;
+    std::vector<char> &lifted_ok = L.lifted_ok;
+    if (nsph > 0) {
+        std::vector<float> med[3];
+        for (int i = 0; i < nsph; ++i) {
+            med[0].push_back(sph[(size_t)i].x); med[1].push_back(sph[(size_t)i].y); med[2].push_back(sph[(size_t)i].z);
+        }
+        float t[3];
+        for (int a = 0; a < 3; ++a) {
+            std::nth_element(med[a].begin(), med[a].begin() + nsph / 2, med[a].end());
+            t[a] = med[a][(size_t)(nsph / 2)];
+            if (!std::isfinite(t[a])) t[a] = 0.0f;
+        }
+        frame.tx = t[0]; frame.ty = t[1]; frame.tz = t[2];
+        std::vector<double> ext;
+        for (int i = 0; i < nsph; ++i) {
+            const float4 &q = sph[(size_t)i];
+            double e = std::max(std::fabs((double)q.x - t[0]), std::max(std::fabs((double)q.y - t[1]), std::fabs((double)q.z - t[2]))) +
+                       std::fabs((double)q.w);
+            ext.push_back(std::isfinite(e) ? e : 0.0);
+        }
+        size_t k95 = (size_t)((double)(nsph - 1) * 0.95);
+        std::nth_element(ext.begin(), ext.begin() + (long)k95, ext.end());
+        double e95 = ext[k95];
+        int ex = (e95 > 0.0 && std::isfinite(e95)) ? (int)std::floor(std::log2(42.5 / e95)) : 0;
+        ex = std::max(-60, std::min(60, ex));
+        frame.sigma = std::ldexp(1.0f, ex);
+        const int nblocks = (nsph + 63) / 64;
+        sphm.assign((size_t)nblocks * 64 * kLiftSlots, (_Float16)0.0f);
+        std::vector<double> room;
+        lifted_ok.assign((size_t)nsph, 0);
+        for (int i = 0; i < nblocks * 64; ++i) {
+            _Float16 slots[kLiftSlots];
+            if (i < nsph) {
+                const float4 &q = sph[(size_t)i];
+                if (lift_sphere(q.x, q.y, q.z, q.w, frame, (double)kMfmaSlack, slots)) {
+                    lifted_ok[(size_t)i] = 1;
+                    const double g = frame.sigma;
+                    const double x = ((double)q.x - t[0]) * g, y = ((double)q.y - t[1]) * g, z = ((double)q.z - t[2]) * g, r2 = (double)q.w * g * ((double)q.w * g);
+                    room.push_back(r2 / (double)kMfmaSlack - (x * x + y * y + z * z) - r2);
+                } else {
+                    ++outliers;
+                }
+            } else {
+                lift_constant(false, slots);
+            }
+            for (int k = 0; k < kLiftSlots; ++k) sphm[lift_index(i / 64, i % 64, k)] = slots[k];
+        }
+        if (!room.empty() && outliers <= std::max(2, nsph / 16)) {
+            size_t k = room.size() / 10;
+            std::nth_element(room.begin(), room.begin() + (long)k, room.end());
+            double lim = std::min(room[k], 57000.0);
+            if (lim > 0.0) oo_limit_m = (float)lim;
+        }
+    }
+    return L;
+}
+
 TileSet build_tiles(const std::vector<float4> &sph, const std::vector<int> &sph_obj, int nsph) {
     TileSet T;
     if (nsph <= 0) return T;
@@ -814,68 +888,13 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n, bool *cache_hit = nullp
         double lim = budget[k];  // 10th percentile: 90 % of the spheres keep their inflation below 25 %
         oo_limit = lim > 0.0 ? (float)std::min(lim, 1e30) : -1.0f;
     }
-    // Matrix-core filter (rt_lift.hpp): frame = median centre and a power-of-two scale that puts the 95th
-    // percentile of |c - T|_inf + r near 42 (of the 244 that the FP16 range allows for a ray origin), lifted
-    // records in A-operand order, and the origin limit: the hard range limit, or less when 10 % of the spheres
-    // would see their filter radius^2 doubled by the slack.
-    std::vector<_Float16> sphm;
-    LiftFrame frame = {0.0f, 0.0f, 0.0f, 1.0f};
-    float oo_limit_m = -1.0f;
-    int outliers = 0;
-    std::vector<char> lifted_ok;
-    if (nsph > 0) {
-        std::vector<float> med[3];
-        for (int i = 0; i < nsph; ++i) {
-            med[0].push_back(sph[(size_t)i].x); med[1].push_back(sph[(size_t)i].y); med[2].push_back(sph[(size_t)i].z);
-        }
-        float t[3];
-        for (int a = 0; a < 3; ++a) {
-            std::nth_element(med[a].begin(), med[a].begin() + nsph / 2, med[a].end());
-            t[a] = med[a][(size_t)(nsph / 2)];
-            if (!std::isfinite(t[a])) t[a] = 0.0f;
-        }
-        frame.tx = t[0]; frame.ty = t[1]; frame.tz = t[2];
-        std::vector<double> ext;
-        for (int i = 0; i < nsph; ++i) {
-            const float4 &q = sph[(size_t)i];
-            double e = std::max(std::fabs((double)q.x - t[0]), std::max(std::fabs((double)q.y - t[1]), std::fabs((double)q.z - t[2]))) +
-                       std::fabs((double)q.w);
-            ext.push_back(std::isfinite(e) ? e : 0.0);
-        }
-        size_t k95 = (size_t)((double)(nsph - 1) * 0.95);
-        std::nth_element(ext.begin(), ext.begin() + (long)k95, ext.end());
-        double e95 = ext[k95];
-        int ex = (e95 > 0.0 && std::isfinite(e95)) ? (int)std::floor(std::log2(42.5 / e95)) : 0;
-        ex = std::max(-60, std::min(60, ex));
-        frame.sigma = std::ldexp(1.0f, ex);
-        const int nblocks = (nsph + 63) / 64;
-        sphm.assign((size_t)nblocks * 64 * kLiftSlots, (_Float16)0.0f);
-        std::vector<double> room;
-        lifted_ok.assign((size_t)nsph, 0);
-        for (int i = 0; i < nblocks * 64; ++i) {
-            _Float16 slots[kLiftSlots];
-            if (i < nsph) {
-                const float4 &q = sph[(size_t)i];
-                if (lift_sphere(q.x, q.y, q.z, q.w, frame, (double)kMfmaSlack, slots)) {
-                    lifted_ok[(size_t)i] = 1;
-                    const double g = frame.sigma;
-                    const double x = ((double)q.x - t[0]) * g, y = ((double)q.y - t[1]) * g, z = ((double)q.z - t[2]) * g, r2 = (double)q.w * g * ((double)q.w * g);
-                    room.push_back(r2 / (double)kMfmaSlack - (x * x + y * y + z * z) - r2);
-                } else {
-                    ++outliers;
-                }
-            } else {
-                lift_constant(false, slots);
-            }
-            for (int k = 0; k < kLiftSlots; ++k) sphm[lift_index(i / 64, i % 64, k)] = slots[k];
-        }
-        if (!room.empty() && outliers <= std::max(2, nsph / 16)) {
-            size_t k = room.size() / 10;
-            std::nth_element(room.begin(), room.begin() + (long)k, room.end());
-            double lim = std::min(room[k], 57000.0);
-            if (lim > 0.0) oo_limit_m = (float)lim;
-        }
-    }
+    // matrix-core filter of the staged kind: frame, lifted records, origin limit
+    LiftSet lifted_set = lift_setup(sph, nsph);
+    std::vector<_Float16> &sphm = lifted_set.sphm;
+    const LiftFrame frame = lifted_set.frame;
+    const float oo_limit_m = lifted_set.oo_limit_m;
+    const int outliers = lifted_set.outliers;
+    const std::vector<char> &lifted_ok = lifted_set.lifted_ok;
     const NarrowSet narrow = narrow_setup(sph, nsph, lifted_ok, frame, oo_limit_m);
     TileSet tileset = build_tiles(sph, sph_obj, nsph);
     while ((int)sph.size() < nslots) {
@@ -1732,6 +1751,29 @@ RT_API int rt_group_bounds(const float *spheres_xyzr, int count, float *out) {
     const std::vector<float4> b = word_bounds(sph, count);
     if (!b.empty()) std::memcpy(out, b.data(), b.size() * sizeof(float4));
     return (int)(b.size() / (size_t)kBoundVec4);
+}
+
+RT_API int rt_filter_box(const float *spheres_xyzr, int count, float out[RT_FILTER_BOX_FLOATS]) {
+    static_assert(RT_FILTER_BOX_FLOATS == 8 + 3 * kWideWords, "rt_amd.h and rt_kernels.h disagree about the record");
+    if (count < 0 || (count > 0 && !spheres_xyzr) || !out) return RT_ERR_INVALID;
+    std::vector<float4> sph((size_t)count);
+    for (int i = 0; i < count; ++i)
+        sph[(size_t)i] = make_float4(spheres_xyzr[4 * i], spheres_xyzr[4 * i + 1], spheres_xyzr[4 * i + 2], spheres_xyzr[4 * i + 3]);
+    const LiftSet L = lift_setup(sph, count);
+    const NarrowSet N = narrow_setup(sph, count, L.lifted_ok, L.frame, L.oo_limit_m);
+    for (int i = 0; i < RT_FILTER_BOX_FLOATS; ++i) out[i] = 0.0f;
+    if (!N.ok) return 0;
+    out[0] = N.mid.x; out[1] = N.mid.y; out[2] = N.mid.z;
+    out[3] = N.half.x; out[4] = N.half.y; out[5] = N.half.z;
+    out[6] = std::sqrt(N.oo) / L.frame.sigma;  // in scene units
+    out[7] = (float)N.words;
+    for (int k = 0; k < kWideWords; ++k) {
+        uint32_t w = N.word[k], t = N.test[k], a = N.always[k];
+        std::memcpy(&out[8 + 3 * k], &w, 4);
+        std::memcpy(&out[9 + 3 * k], &t, 4);
+        std::memcpy(&out[10 + 3 * k], &a, 4);
+    }
+    return 1;
 }
 
 RT_API int rt_trace_times(rt_ctx *ctx, float *ms, int cap, int *count) {

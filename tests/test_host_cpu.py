@@ -276,3 +276,37 @@ def test_matrix_results_are_read_at_a_safe_distance():
     assert out.returncode == 0, out.stdout + out.stderr
     checked = int(out.stdout.strip().splitlines()[-1].split()[0])
     assert checked >= 32  # the trace kernels of both matrix-core kinds and the self-test were seen
+
+
+def test_filter_box_holds_the_ordinary_spheres_and_lists_the_others(rt):
+    """The box of the half-width sphere filter (host logic, rt_filter_box): it holds every ordinary sphere with room to
+    spare, the spheres much larger than the rest and those the lifted form cannot hold are listed word by word, and
+    scenes the path is not meant for get none."""
+    objs, n = rt.scene("cover")
+    sph = np.array([[o.s.center.x, o.s.center.y, o.s.center.z, o.s.radius] for o in objs[:n]], np.float32)
+    box = rt.filter_box(sph)
+    assert box is not None
+    # cover scene: the ground (slot 0, no filter can hold it) and the three spheres of radius 1 (slots 484..486, tested)
+    assert box["words"] == [(0, 0, 0x80000000), (15, 0x0E000000, 0)], box["words"]
+    ordinary = sph[1:484]
+    lo, hi = box["mid"] - box["half"], box["mid"] + box["half"]
+    grown = ordinary[:, 3:4] * 1.0001
+    assert np.all(ordinary[:, :3] - grown > lo) and np.all(ordinary[:, :3] + grown < hi)
+    assert np.all(box["half"] < 1.2 * (ordinary[:, :3].max(0) - ordinary[:, :3].min(0) + 2 * ordinary[:, 3].max()) / 2 + 0.2)   # and is no larger than it must be
+    assert box["half"][1] < 0.4           # the layer of small spheres is 0.4 high: a flat box
+    assert box["reach"] > 30.0            # origins well beyond the camera's 13.5 units
+    # fewer than 128 spheres; nine large spheres; large spheres spread over five words: no box
+    assert rt.filter_box(sph[:100]) is None
+    many = np.vstack([sph, [[3.0 * k, 2.0, 9.0, 2.0] for k in range(6)]]).astype(np.float32)
+    assert rt.filter_box(many) is None
+    spread = sph.copy()
+    for slot in (40, 100, 200):
+        spread[slot, 3] = 1.0
+    assert rt.filter_box(spread) is None
+    # a sphere that can never be hit (NaN) is neither in the box nor looked at
+    odd = sph.copy()
+    odd[300] = [np.nan, 0.2, 1.0, 0.2]
+    box = rt.filter_box(odd)
+    assert box is not None and (300 // 32, 0, 0) in [(w, t, a) for w, t, a in box["words"]]
+    assert np.all(np.isfinite(box["mid"])) and np.all(np.isfinite(box["half"]))
+    assert rt.amd_lib().rt_filter_box(None, -1, None) < 0
