@@ -144,6 +144,30 @@ def test_tiled_matrix_filter_awkward_spheres_bit_exact(rt, oracle, renderer):
         assert np.array_equal(bits(img), bits(want)), (fetch, narrow)
 
 
+@pytest.mark.parametrize("eye,fov", [((2600.0, 400.0, 600.0), 0.6), ((3.0, 0.15, 2.0), 70.0), ((0.0, 60.0, 0.1), 25.0)])
+def test_tiles_read_in_place_from_far_near_and_above(rt, oracle, renderer, eye, fov):
+    """The boxes of the tiled kind that reads its tiles in place take their allowances from each ray's distance: a
+    camera thousands of radii away (narrow view, so that the rays still find the spheres), one between the spheres, and
+    one looking straight down -- against the oracle, and against the tiles streamed through LDS."""
+    strict(renderer, rt)
+    w, h, spp = 96, 54, 3
+    objs, n = rt.scene("random_spheres", n=4000, extent=16.0)
+    u = rt.config_uniforms("random_spheres", w, h, spp, 50, n)
+    f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+    rt.host_lib().rt_camera_setup(C.byref(u), f3(eye), f3((0.0, 0.2, 0.0)), f3([0, 1, 0]), fov, 0.0, 10.0, w, h)
+    renderer.setupTexture(w, h)
+    want = oracle.image(u, objs, w, h)
+    assert len(np.unique(bits(want).reshape(-1, 4), axis=0)) > 50
+    try:
+        for narrow, path in ((1, 5), (0, 4)):
+            renderer.set_option(rt.RT_OPT_NARROW, narrow)
+            img = renderer.renderImage(u, objs, n)
+            assert renderer.lastStats().scene_path == path
+            assert np.array_equal(bits(img), bits(want)), narrow
+    finally:
+        renderer.set_option(rt.RT_OPT_NARROW, 1)
+
+
 def test_tiled_and_vector_filters_agree_on_100k_spheres(rt, renderer):
     """The 100 000-sphere configuration at 640x360 x 4 spp, beyond what the oracle checks in seconds: lifted tiles read
     in place (default, twice: run-to-run determinism) and streamed through LDS against the vector filter through the
