@@ -28,8 +28,8 @@ constexpr int kMaskWordsPerWave = kBestOffset + 128; // LDS words per wave
 #endif
 constexpr int kRestPooled = RT_REST_POOLED;  // dense rounds: candidates in the whole wave after the prune up to which the pooled form resolves them
 constexpr int kRestPerLane = 12;   // dense rounds: candidates per lane after the prune up to which every lane resolves its own
-constexpr int kFewRays = RT_FEW_RAYS;  // tiled kind read in place: rays of a wave that touch a tile up to which every lane tests eight of the tile's spheres
-                                       // exactly for one ray after the other (closest_sphere_direct); more go through the matrix-core filter
+constexpr int kFewRays = RT_FEW_RAYS;  // tiled kind read in place: rays of a wave that touch a tile up to which every lane tests its share of the tile's
+                                       // slots exactly for one ray after the other (closest_sphere_direct); more go through the matrix-core filter
 constexpr int kDenseWordBits = 8;  // candidates in a word of 32 spheres from which the word counts as dense (closest_sphere)
 
 // Filter margins (see closest_sphere).  kDirScale inflates the b side of both filters; the c side is inflated
@@ -583,8 +583,8 @@ RT_DEV uint32_t filter_round_matrix(const h8 *pm, int blk0, int blk1, uint32_t *
 // the lifted form; the host lists them) are tested for every ray by the general vector filter afterwards.
 //
 // Conservativeness.  Whenever the reference's discriminant is >= 0 the ray's line passes within
-// sqrt(r^2 + 17u |o - c|^2) of the centre (closest_sphere), and the accepted root's point lies within the same
-// distance of it up to another 17u |o - c|^2 under the root; the host grows every sphere's radius to
+// sqrt(r^2 + 17u |o - c|^2) of the centre (closest_sphere), and the point of an accepted root lies within
+// sqrt(r^2 + 34u |o - c|^2) of it; the host grows every sphere's radius to
 // sqrt(r^2 + 64u D^2) with D >= |o - c| for every origin this path admits (TraceParams::narrow_oo) before it takes the
 // box, and pads the box for the roundings of the test itself (rt_api.hip narrow_setup).  The test declares a miss only
 // on a separating axis of line and box (the three cross products of the direction with the box axes) or when the
