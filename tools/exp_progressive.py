@@ -1,7 +1,7 @@
 """Throughput of the reference's own call shape: one blocking rt_render_tile per 64x64 tile (ContentView.swift:628-709),
 cover scene at 1920x1080 (510 tiles), one pass.  Measured twice: the same Object[] re-sent on every call (the library
 recognises it and keeps the compacted scene), and one byte of it changed between calls (every call rebuilds the scene:
-compaction, FP16 lift, uploads -- what every call did before the comparison was added)."""
+compaction, FP16 lift, uploads -- what every call did before the comparison was added).  NARROW=0/1: RT_OPT_NARROW."""
 import ctypes as C
 import os
 import sys
@@ -16,6 +16,8 @@ objs, n = rt.scene("cover")
 r = rt.MetalRenderer(0)
 r.setupTexture(W, H)
 r.generateTiles()
+if os.environ.get("NARROW"):
+    r.set_option(rt.RT_OPT_NARROW, int(os.environ["NARROW"]))
 u = rt.config_uniforms("cover", W, H, spp, 50, n)
 lib, ctx = r._lib, r._ctx
 raw = (C.c_ubyte * (160 * n)).from_buffer(objs)
