@@ -280,10 +280,11 @@ RT_API int rt_filter_box(const float *spheres_xyzr, int count, float out[RT_FILT
 RT_API int rt_selftest_box(rt_ctx *ctx, uint32_t seed, int blocks, int rays_per_thread, int padding_log2, uint64_t out[6]);
 
 /* No counterpart in the reference.  The same for the boxes of the tiled kind that reads its tiles in place (scenes beyond
- * 1024 spheres, or RT_OPT_SCENE_FETCH 3): a ray that the box of a tile, or of its group of 64 tiles, leaves out must have
- * no accepted root on any sphere of that tile.  Origins on, near or up to 2^12 radii away from a sphere, or on a face of
- * a tile's box.  padding_log2 scales the allowances that grow with the ray's distance (0: as rendered with; -40: none).
- * out as rt_selftest_box, out[1] counting (ray, tile) pairs left out. */
+ * 1024 spheres, or RT_OPT_SCENE_FETCH 3): a ray that the box of a tile, of its group of 64 tiles, or of one of the tile's
+ * blocks of 64 sphere slots leaves out must have no accepted root on any sphere of that tile or block.  Origins on, near
+ * or up to 2^12 radii away from a sphere, or on a face of a tile's box.  padding_log2 scales the allowances that grow with
+ * the ray's distance (0: as rendered with; -40: none).  out as rt_selftest_box, out[1] counting (ray, tile) pairs left
+ * out, out[5] (ray, block) pairs left out. */
 RT_API int rt_selftest_tile_boxes(rt_ctx *ctx, uint32_t seed, int blocks, int rays_per_thread, int padding_log2, uint64_t out[6]);
 
 /* No counterpart in the reference.  Host-only (no device, no context): the bounding balls the library builds at scene

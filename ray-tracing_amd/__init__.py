@@ -532,7 +532,7 @@ class MetalRenderer:
         """On the scene set with setScene."""
         out = (C.c_uint64 * 6)()
         self._check(self._lib.rt_selftest_tile_boxes(self._ctx, seed, blocks, rays_per_thread, padding_log2, out))
-        return dict(zip(["rays", "left_out", "pairs", "roots", "wrong"], list(out)))
+        return dict(zip(["rays", "left_out", "pairs", "roots", "wrong", "blocks_left_out"], list(out)))
 
     def selftestTiledFilter(self, seed=1, blocks=1024, rounds=64, slack_log2=-16):
         out = (C.c_uint64 * 6)()

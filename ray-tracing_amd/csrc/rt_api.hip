@@ -441,12 +441,36 @@ TileSet build_tiles(const std::vector<float4> &sph, const std::vector<int> &sph_
         rmax = std::max(rmax, (double)sph[(size_t)i].w);
     }
     if (!B.ids.empty()) B.split(0, (int)B.ids.size());
-    // tile contents in slot order.  Inside a tile: descending object index -- the tie rule of the exact pass, not the
-    // visiting order, is what gives an equal distance to the lower index, and this keeps that rule exercised.
+    // tile contents in slot order.  Inside a block of 64 slots: descending object index -- the tie rule of the exact
+    // pass, not the visiting order, is what gives an equal distance to the lower index, and this keeps that rule exercised ...
     std::vector<std::vector<int>> members;
+    // ... and before that, blocks of 64 slots whose spheres are neighbours in space (each block gets a box of its own
+    // below): median splits along the widest axis of the centres, whole blocks to the left.
+    std::function<void(std::vector<int> &, int, int)> order_blocks = [&](std::vector<int> &m, int lo_i, int hi_i) {
+        const int nb = (hi_i - lo_i + 63) / 64;
+        if (nb <= 1) {
+            std::sort(m.begin() + lo_i, m.begin() + hi_i, std::greater<int>());
+            return;
+        }
+        double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+        for (int k = lo_i; k < hi_i; ++k) {
+            const float4 &q = sph[(size_t)m[(size_t)k]];
+            const double c[3] = {q.x, q.y, q.z};
+            for (int a = 0; a < 3; ++a) { blo[a] = std::min(blo[a], c[a]); bhi[a] = std::max(bhi[a], c[a]); }
+        }
+        int axis = 0;
+        for (int a = 1; a < 3; ++a)
+            if (bhi[a] - blo[a] > bhi[axis] - blo[axis]) axis = a;
+        const int mid = lo_i + ((nb + 1) / 2) * 64;
+        auto key = [&](int i) { const float4 &q = sph[(size_t)i]; return axis == 0 ? q.x : axis == 1 ? q.y : q.z; };
+        std::nth_element(m.begin() + lo_i, m.begin() + mid, m.begin() + hi_i,
+                         [&](int p, int q) { return key(p) < key(q) || (key(p) == key(q) && p < q); });
+        order_blocks(m, lo_i, mid);
+        order_blocks(m, mid, hi_i);
+    };
     for (auto &lf : B.leaves) {
-        std::vector<int> m(B.ids.begin() + lf.first, B.ids.begin() + lf.second);
-        std::sort(m.begin(), m.end(), std::greater<int>());
+        std::vector<int> m(B.ids.begin() + lf.first, B.ids.begin() + lf.second);   // regular spheres only: finite centres
+        order_blocks(m, 0, (int)m.size());
         members.push_back(m);
     }
     for (int i : irregular) {
@@ -466,6 +490,7 @@ TileSet build_tiles(const std::vector<float4> &sph, const std::vector<int> &sph_
     T.frames.assign((size_t)T.ntiles * kTileFrameVec4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     T.obj.assign((size_t)T.ntiles * kTileSpheres, -1);
     int outliers = 0;
+    std::vector<float4> block_boxes;   // appended to T.frames after the groups' boxes
     for (int t = 0; t < T.ntiles; ++t) {
         const std::vector<int> &m = members[(size_t)t];
         const int count = (int)m.size();
@@ -484,6 +509,12 @@ TileSet build_tiles(const std::vector<float4> &sph, const std::vector<int> &sph_
         double cmax = 0.0;  // largest |c'| among the spheres of the tile that are filtered (lift_ray_near)
         double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
         bool boxed = true;
+        double klo[kTileBlocks][3], khi[kTileBlocks][3];   // the same per block of 64 slots
+        bool kboxed[kTileBlocks];
+        for (int k = 0; k < kTileBlocks; ++k) {
+            kboxed[k] = true;
+            for (int a = 0; a < 3; ++a) { klo[k][a] = 1e300; khi[k][a] = -1e300; }
+        }
         for (int j = 0; j < kTileSpheres; ++j) {
             _Float16 slots[kLiftSlots];
             if (j < count) {
@@ -499,10 +530,13 @@ TileSet build_tiles(const std::vector<float4> &sph, const std::vector<int> &sph_
                     for (int a = 0; a < 3; ++a) {
                         blo[a] = std::min(blo[a], c[a] - std::fabs((double)q.w));
                         bhi[a] = std::max(bhi[a], c[a] + std::fabs((double)q.w));
+                        klo[j / 64][a] = std::min(klo[j / 64][a], c[a] - std::fabs((double)q.w));
+                        khi[j / 64][a] = std::max(khi[j / 64][a], c[a] + std::fabs((double)q.w));
                     }
                 } else {
                     ++outliers;
                     boxed = false;
+                    kboxed[j / 64] = false;
                 }
             } else {
                 strict[j] = make_float4(0.0f, 0.0f, 0.0f, std::numeric_limits<float>::quiet_NaN());  // never a hit
@@ -518,13 +552,15 @@ TileSet build_tiles(const std::vector<float4> &sph, const std::vector<int> &sph_
         // that depend on the ray's distance are added there).  Only spheres the lifted form holds can be left to a box:
         // any other member (never hit, or a candidate for every ray) makes the box infinite.
         const float inf = std::numeric_limits<float>::infinity();
-        float4 bmid = make_float4(0.0f, 0.0f, 0.0f, 0.0f), bhalf = make_float4(inf, inf, inf, 0.0f);
-        if (boxed && count > 0) {
+        auto box_of = [&](const double *lo3, const double *hi3, bool ok, float4 &bmid, float4 &bhalf) {
+            bmid = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            bhalf = make_float4(inf, inf, inf, 0.0f);
+            if (!ok) return;
             float mid[3], half[3];
             double diag2 = 0.0;
             for (int a = 0; a < 3; ++a) {
-                mid[a] = (float)(0.5 * (blo[a] + bhi[a]));
-                const double h = std::max(bhi[a] - (double)mid[a], (double)mid[a] - blo[a]);
+                mid[a] = (float)(0.5 * (lo3[a] + hi3[a]));
+                const double h = std::max(hi3[a] - (double)mid[a], (double)mid[a] - lo3[a]);
                 half[a] = std::nextafterf((float)(h * (1.0 + 0x1p-12)), inf);
                 diag2 += (double)half[a] * (double)half[a];
             }
@@ -532,9 +568,15 @@ TileSet build_tiles(const std::vector<float4> &sph, const std::vector<int> &sph_
                 bmid = make_float4(mid[0], mid[1], mid[2], std::nextafterf((float)std::sqrt(diag2), inf));
                 bhalf = make_float4(half[0], half[1], half[2], 0.0f);
             }
+        };
+        box_of(blo, bhi, boxed && count > 0, T.frames[(size_t)kTileFrameVec4 * t + 2], T.frames[(size_t)kTileFrameVec4 * t + 3]);
+        // ... and around the spheres of each of its blocks of 64 slots (a block without spheres is never looked at)
+        for (int k = 0; k < kTileBlocks; ++k) {
+            float4 bm, bh;
+            box_of(klo[k], khi[k], kboxed[k] && 64 * k < count, bm, bh);
+            block_boxes.push_back(bm);
+            block_boxes.push_back(bh);
         }
-        T.frames[(size_t)kTileFrameVec4 * t + 2] = bmid;
-        T.frames[(size_t)kTileFrameVec4 * t + 3] = bhalf;
     }
     // a box around every group of kTileGroup consecutive tiles (the leaves of the median splits in order: neighbours in space)
     for (int t0 = 0; t0 < T.ntiles; t0 += kTileGroup) {
@@ -567,6 +609,7 @@ TileSet build_tiles(const std::vector<float4> &sph, const std::vector<int> &sph_
         T.frames.push_back(bmid);
         T.frames.push_back(bhalf);
     }
+    T.frames.insert(T.frames.end(), block_boxes.begin(), block_boxes.end());
     T.ok = outliers <= std::max(2, nsph / 16);  // else pass B would do most of the work
     return T;
 }

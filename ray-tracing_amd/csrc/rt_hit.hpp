@@ -608,11 +608,13 @@ RT_DEV bool ray_may_touch_box(V3 o, V3 d, V3 m, V3 h) {
 
 // The same for a box the ray may start any distance from (the tiled kinds): bm = (centre, length of the half diagonal),
 // bh = half extents, already widened by 1 + 2^-12 on the host.  The allowances are taken per ray from
-// D = |o - centre| + half diagonal, which bounds |o - c| for every sphere centre c in the box: a radius grows to
-// sqrt(r^2 + 64u D^2) <= r + 2^-9 D, and the test's own roundings are within 2^-16 D.  scale (self-test only) scales both.
+// D >= |o - centre| + half diagonal, which bounds |o - c| for every sphere centre c in the box: a radius grows to
+// sqrt(r^2 + 64u D^2) <= r + 2^-9 D, and the test's own roundings are within 2^-16 D.  (The distance is taken as the sum
+// of the three absolute differences, which is never below the Euclidean one and costs two additions.)  scale (self-test
+// only) scales both allowances.
 RT_DEV bool ray_may_touch_far_box(V3 o, V3 d, f4v bm, f4v bh, float scale = 1.0f) {
     const float ex = o.x - bm.x, ey = o.y - bm.y, ez = o.z - bm.z;
-    const float dist = __builtin_sqrtf(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex))) * (1.0f + 0x1p-20f) + bm.w;
+    const float dist = __builtin_fmaf(__builtin_fabsf(ex) + __builtin_fabsf(ey) + __builtin_fabsf(ez), 1.0f + 0x1p-20f, bm.w);
     const float pad = dist * ((0x1p-9f * (1.0f + 0x1p-6f) + 0x1p-16f) * scale);
     return ray_may_touch_box(o, d, v3(bm.x, bm.y, bm.z), v3(bh.x + pad, bh.y + pad, bh.z + pad));
 }
@@ -1713,8 +1715,8 @@ RT_DEV int closest_sphere_tiled(const TraceParams &P, Fetch<kFetchTiled> &f, uin
 //   every lane asks whether its own ray can touch the group's box;
 //   lane j takes the box of the group's tile j and is asked about those rays one after the other (or, in a group of
 //   fewer tiles than rays, every lane is asked about its own ray, tile after tile);
-//   the wave then visits the tiles some ray touches.  For up to kFewRays rays every lane tests eight of the tile's
-//   slots exactly, ray after ray; more rays (up to 32) are gathered into one ray tile and the matrix-core filter runs
+//   the wave then visits the tiles some ray touches.  For up to kFewRays rays every lane tests its slots of the blocks
+//   of 64 that the ray can touch (each block has a box too) exactly, ray after ray; more rays (up to 32) are gathered into one ray tile and the matrix-core filter runs
 //   at half width (filter_round_narrow), beyond that at full width, its sphere operands read from global memory --
 //   from the L2 and Infinity caches, which hold the whole scene: 196 tiles of 40 KB for 100 000 spheres.
 // Nothing is staged and no wave waits for another.
@@ -1731,6 +1733,7 @@ RT_DEV int closest_sphere_direct(const TraceParams &P, Fetch<kFetchTiledDirect> 
     float nskip = __builtin_inff();
     const const_f4_ptr frames = (const_f4_ptr)(uintptr_t)P.tile_frames;
     const const_f4_ptr groups = frames + kTileFrameVec4 * P.ntiles;
+    const f4v *const block_boxes = (const f4v *)P.tile_frames + kTileFrameVec4 * P.ntiles + 2 * ((P.ntiles + kTileGroup - 1) / kTileGroup);
     const bool live = active && a_ok;
     if (__builtin_amdgcn_ballot_w64(live) == 0) return -1;
     auto bcast = [](float v, int l) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
@@ -1784,10 +1787,16 @@ RT_DEV int closest_sphere_direct(const TraceParams &P, Fetch<kFetchTiledDirect> 
                 // not depend on the best so far).
                 // (Asking for the next visited tile's records while this one is worked on was measured: the second set of
                 // registers spills, -29 % with tiles of 512 slots, -6 % with 256.)
-                constexpr int kPerLane = kTileSpheres / 64;
+                // The tile's slots are ordered so that each block of 64 holds neighbours in space, and each block has a
+                // box of its own: lane k holds the box of block k, is asked about the ray, and the wave tests the ray
+                // against the blocks it can touch only (one or two of the eight, mostly).
+                constexpr int kPerLane = kTileBlocks;
                 f4v rec[kPerLane];
 #pragma unroll
                 for (int i = 0; i < kPerLane; ++i) rec[i] = tile[kTileLifted + 64 * i + lane];
+                const f4v *kb = block_boxes + 2 * (t * kTileBlocks + (lane & (kTileBlocks - 1)));
+                const f4v kbm = kb[0], kbh = kb[1];
+                const bool holds_block = lane < ((int)fb.y + 63) / 64;
                 unsigned long long *offer = (unsigned long long *)(wave_masks + kBestOffset);
                 if (touch) offer[lane] = ~0ull;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1801,8 +1810,11 @@ RT_DEV int closest_sphere_direct(const TraceParams &P, Fetch<kFetchTiledDirect> 
                     q.r = bcast(dv.r, L);
                     q.nmin = q.a * 0.0009f;
                     q.slow = dv.slow;
+                    const uint32_t blocks = (uint32_t)__builtin_amdgcn_ballot_w64(holds_block && ray_may_touch_far_box(ro, rd, kbm, kbh));
+                    if constexpr (PROF) prof.count(7, 64u * (uint32_t)__builtin_popcount(blocks));
 #pragma unroll
                     for (int i = 0; i < kPerLane; ++i) {
+                        if (((blocks >> i) & 1u) == 0u) continue;   // (wave-uniform)
                         const float ocx = ro.x - rec[i].x, ocy = ro.y - rec[i].y, ocz = ro.z - rec[i].z;
                         const float b = ocx * rd.x + ocy * rd.y + ocz * rd.z;
                         const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - rec[i].w * rec[i].w;
@@ -1816,7 +1828,6 @@ RT_DEV int closest_sphere_direct(const TraceParams &P, Fetch<kFetchTiledDirect> 
                             }
                         }
                     }
-                    if constexpr (PROF) prof.count(7, kTileSpheres);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();

@@ -24,6 +24,7 @@ constexpr int kTileLifted = kTileSpheres * 4;          // float4 of lifted A ope
 constexpr int kTileVec4 = kTileLifted + kTileSpheres;  // ... followed by the strict records
 constexpr int kTileFrameVec4 = 4;                      // float4 per tile in TraceParams::tile_frames
 constexpr int kTileGroup = 64;                         // consecutive tiles that share a box of their own (rt_hit.hpp closest_sphere_direct)
+constexpr int kTileBlocks = kTileSpheres / 64;         // blocks of 64 consecutive slots of a tile, each with a box of its own
 
 // Everything one trace launch needs.  Passed by value in the kernel argument segment.  The first block is
 // read on every trip of the kernel's main loop and lives in scalar registers; the kernel reads the second
@@ -52,7 +53,9 @@ struct TraceParams {
                                 // largest |c'| of a filtered sphere, 0), (centre of the box around the tile's spheres,
                                 // length of its half diagonal), (its half extents x (1 + 2^-12), 0); a tile with a sphere
                                 // no box can stand for: infinite half extents.  After the tiles: the same two float4 (box
-                                // centre and half diagonal, half extents) for every group of kTileGroup consecutive tiles
+                                // centre and half diagonal, half extents) for every group of kTileGroup consecutive tiles,
+                                // and after those for each of the kTileBlocks blocks of 64 slots of every tile (a tile's
+                                // slots are ordered so that a block's spheres are neighbours in space)
     const int *tile_obj;    // [ntiles * 512] object index of each slot in tile order (-1: padding)
     int ntiles;
     int stage_mats;         // matrix-core kind: sph_obj and mats are staged in LDS too (the launch reserved the room)

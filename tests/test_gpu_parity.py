@@ -1137,13 +1137,13 @@ def test_box_test_leaves_out_no_ray_the_reference_would_hit_with(rt, renderer, k
 
 @pytest.mark.parametrize("n,extent", [(5000, 20.0), (20000, 22.0)])
 def test_tile_boxes_leave_out_no_ray_the_reference_would_hit_with(rt, renderer, n, extent):
-    """rt_selftest_tile_boxes: the boxes of the tiles and tile groups of the kind that reads its tiles in place, rays from
-    on a sphere to 2^12 radii away.  No (ray, tile) pair the boxes leave out may hold an accepted root -- with the
-    allowances the library renders with, and with a quarter of them."""
+    """rt_selftest_tile_boxes: the boxes of the tiles, of the tile groups and of the tiles' blocks of 64 slots of the kind
+    that reads its tiles in place, rays from on a sphere to 2^12 radii away.  No (ray, tile) or (ray, block) pair the boxes
+    leave out may hold an accepted root -- with the allowances the library renders with, and with a quarter of them."""
     arr, n = rt.scene("random_spheres", n=n, extent=extent)
     renderer.setScene(arr, n)
     for padding in (0, -2):
-        tot = {"rays": 0, "left_out": 0, "pairs": 0, "roots": 0}
+        tot = {"rays": 0, "left_out": 0, "pairs": 0, "roots": 0, "blocks_left_out": 0}
         for seed in (1, 2):
             r = renderer.selftestTileBoxes(seed=seed, blocks=256 if n < 10000 else 64, rays_per_thread=2, padding_log2=padding)
             assert r["wrong"] == 0, (padding, r)
@@ -1151,6 +1151,7 @@ def test_tile_boxes_leave_out_no_ray_the_reference_would_hit_with(rt, renderer, 
                 tot[k] += r[k]
         assert tot["rays"] > 3e4 and tot["roots"] > tot["rays"]
         assert tot["left_out"] > 3 * tot["rays"], tot      # most tiles are left out for most rays
+        assert tot["blocks_left_out"] > 7 * tot["left_out"], tot   # ... and of the others, some of their blocks
 
 
 def test_default_path_of_the_cover_scene_is_the_matrix_filter(rt, renderer):
