@@ -213,10 +213,12 @@ struct Fetch<kFetchTiledDirect> {  // the lifted tiles read in place (closest_sp
     static constexpr bool kTiled = true;
     static constexpr bool kScalarRecords = false;
     const f4v *tiles;    // global
+    f4v *rays;           // LDS, this wave's: [2][64] (origin, d.d) and (direction, refined reciprocal of d.d) of every lane's ray
     RT_DEV f4v load1(int k) const { return tiles[(size_t)(k / kTileSpheres) * kTileVec4 + kTileLifted + (k % kTileSpheres)]; }
     RT_DEV int object_of(const TraceParams &P, int slot) const { return P.tile_obj[slot]; }
     RT_DEV MatDev material(const TraceParams &P, int obj) const { return P.mats[obj]; }
 };
+constexpr int kDirectRayVec4 = 128;   // float4 of LDS per wave behind the candidate words of all waves (Fetch<kFetchTiledDirect>::rays)
 
 // The strict records of one tile in LDS, with the interface filter_round expects.
 struct TileStrict {
@@ -1736,7 +1738,17 @@ RT_DEV int closest_sphere_direct(const TraceParams &P, Fetch<kFetchTiledDirect> 
     const f4v *const block_boxes = (const f4v *)P.tile_frames + kTileFrameVec4 * P.ntiles + 2 * ((P.ntiles + kTileGroup - 1) / kTileGroup);
     const bool live = active && a_ok;
     if (__builtin_amdgcn_ballot_w64(live) == 0) return -1;
-    auto bcast = [](float v, int l) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+    // Where one ray is put to all lanes at once (a lane holding a tile's box, or its slots of a tile's blocks), the ray
+    // comes from LDS, every lane reading the same two float4: operands in vector registers (a vector instruction with
+    // a scalar-register source issues at half rate), and the broadcast costs no vector instruction.
+    f4v *const ray_lds = f.rays;
+    if (live) {
+        ray_lds[lane] = f4v{o.x, o.y, o.z, dv.a};
+        ray_lds[64 + lane] = f4v{d.x, d.y, d.z, dv.r};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int t0 = 0; t0 < P.ntiles; t0 += kTileGroup) {
         // the rays that can touch the group's box at all, every lane asking for its own ray
         const uint64_t rays = __builtin_amdgcn_ballot_w64(live && ray_may_touch_far_box(o, d, groups[2 * (t0 / kTileGroup)], groups[2 * (t0 / kTileGroup) + 1]));
@@ -1750,13 +1762,20 @@ RT_DEV int closest_sphere_direct(const TraceParams &P, Fetch<kFetchTiledDirect> 
         uint32_t set_lo = 0, set_hi = 0;
         const int ngroup = min(kTileGroup, P.ntiles - t0);
         if (__builtin_popcountll(rays) < ngroup) {
-            for (uint64_t rest = rays; rest != 0; rest &= rest - 1) {
-                const int L = __builtin_amdgcn_readfirstlane(__builtin_ctzll(rest));
-                const V3 ro = v3(bcast(o.x, L), bcast(o.y, L), bcast(o.z, L)), rd = v3(bcast(d.x, L), bcast(d.y, L), bcast(d.z, L));
-                if (real && ray_may_touch_far_box(ro, rd, bm, bh)) {
+            uint64_t rest = rays;
+            int L = __builtin_amdgcn_readfirstlane(__builtin_ctzll(rest));
+            f4v ra = ray_lds[L], rb = ray_lds[64 + L];
+            while (rest != 0) {
+                rest &= rest - 1;
+                const int Ln = rest != 0 ? __builtin_amdgcn_readfirstlane(__builtin_ctzll(rest)) : L;
+                const f4v na = ray_lds[Ln], nb = ray_lds[64 + Ln];   // the next ray's numbers, asked for before this one's test
+                if (real && ray_may_touch_far_box(v3(ra.x, ra.y, ra.z), v3(rb.x, rb.y, rb.z), bm, bh)) {
                     set_lo |= L < 32 ? 1u << L : 0u;
                     set_hi |= L < 32 ? 0u : 1u << (L - 32);
                 }
+                ra = na;
+                rb = nb;
+                L = Ln;
             }
         } else {
             // fewer tiles than rays: the other way round, every lane asking about its own ray, tile after tile
@@ -1804,10 +1823,11 @@ RT_DEV int closest_sphere_direct(const TraceParams &P, Fetch<kFetchTiledDirect> 
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 for (uint64_t rest = touching; rest != 0; rest &= rest - 1) {
                     const int L = __builtin_amdgcn_readfirstlane(__builtin_ctzll(rest));
-                    const V3 ro = v3(bcast(o.x, L), bcast(o.y, L), bcast(o.z, L)), rd = v3(bcast(d.x, L), bcast(d.y, L), bcast(d.z, L));
+                    const f4v ra = ray_lds[L], rb = ray_lds[64 + L];
+                    const V3 ro = v3(ra.x, ra.y, ra.z), rd = v3(rb.x, rb.y, rb.z);
                     RootDiv q;
-                    q.a = bcast(dv.a, L);
-                    q.r = bcast(dv.r, L);
+                    q.a = ra.w;
+                    q.r = rb.w;
                     q.nmin = q.a * 0.0009f;
                     q.slow = dv.slow;
                     const uint32_t blocks = (uint32_t)__builtin_amdgcn_ballot_w64(holds_block && ray_may_touch_far_box(ro, rd, kbm, kbh));
@@ -1985,7 +2005,8 @@ RT_DEV Camera cold_camera(ColdParams C) {
 //   kFetchScalar: nothing;
 //   kFetchMatrix: lifted A operands, 4 KiB per 64-sphere block, then strict records 4 * (ngroups + 1) x 16 B, then
 //                 (P.stage_mats) the slot -> object table (16-bit) and the material records;
-//   kFetchTiled:  two tile buffers of kTileVec4 x 16 B and four spare records (the vector filter reads one group ahead).
+//   kFetchTiled:  two tile buffers of kTileVec4 x 16 B and four spare records (the vector filter reads one group ahead);
+//   kFetchTiledDirect: per wave kDirectRayVec4 x 16 B for the rays of its lanes.
 template <int KIND>
 RT_DEV void stage_scene(const TraceParams &P, uint32_t *lds_words, uint32_t *&wave_masks, Fetch<KIND> &f) {
     const int wave = threadIdx.x >> 6;
@@ -2026,6 +2047,7 @@ RT_DEV void stage_scene(const TraceParams &P, uint32_t *lds_words, uint32_t *&wa
         f.tiles = (const f4v *)P.tiles;
     } else if constexpr (KIND == kFetchTiledDirect) {
         f.tiles = (const f4v *)P.tiles;
+        f.rays = (f4v *)after_masks + wave * kDirectRayVec4;
     } else if constexpr (KIND == kFetchScalar) {
         f.pc = (const_f4_ptr)(uintptr_t)P.sphc;
         f.pg = (const_f4_ptr)(uintptr_t)P.sphg;
