@@ -74,6 +74,7 @@ struct rt_ctx {
     DevBuf<float4> round_runs;          // the run of shells of every resolve round (TraceParams::round_runs)
     DevBuf<float4> word_bounds;         // balls around and inside every 32 sphere slots (TraceParams::word_bounds)
     DevBuf<int> tile_obj;
+    DevBuf<uint16_t> tile_rank;
     int ntiles = 0;
     bool scene_dense = false;  // lines through the scene cross many spheres (dense_scene): kernels with the lane-by-lane exact pass
     bool tiles_ok = false;     // all but a few spheres can be filtered in their tile (the others go to the exact test for every ray)
@@ -210,6 +211,7 @@ int upload(rt_ctx *ctx, DevBuf<T> &b, const std::vector<T> &h) {
 struct TileSet {
     std::vector<float4> tiles, frames;
     std::vector<int> obj;
+    std::vector<uint16_t> rank;   // TraceParams::tile_rank
     int ntiles = 0;
     bool ok = false;
 };
@@ -489,6 +491,7 @@ TileSet build_tiles(const std::vector<float4> &sph, const std::vector<int> &sph_
     T.tiles.assign((size_t)T.ntiles * kTileVec4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     T.frames.assign((size_t)T.ntiles * kTileFrameVec4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     T.obj.assign((size_t)T.ntiles * kTileSpheres, -1);
+    T.rank.assign((size_t)T.ntiles * 512, 0);   // eight places per lane whatever the tile size
     int outliers = 0;
     std::vector<float4> block_boxes;   // appended to T.frames after the groups' boxes
     for (int t = 0; t < T.ntiles; ++t) {
@@ -514,6 +517,16 @@ TileSet build_tiles(const std::vector<float4> &sph, const std::vector<int> &sph_
         for (int k = 0; k < kTileBlocks; ++k) {
             kboxed[k] = true;
             for (int a = 0; a < 3; ++a) { klo[k][a] = 1e300; khi[k][a] = -1e300; }
+        }
+        {
+            // the place of every slot's object index among the tile's, ascending
+            std::vector<std::pair<int, int>> by_obj;
+            for (int j = 0; j < count; ++j) by_obj.push_back({sph_obj[(size_t)m[(size_t)j]], j});
+            std::sort(by_obj.begin(), by_obj.end());
+            for (int k = 0; k < count; ++k) {
+                const int j = by_obj[(size_t)k].second;
+                T.rank[(size_t)t * 512 + (size_t)(j % 64) * 8 + (size_t)(j / 64)] = (uint16_t)k;
+            }
         }
         for (int j = 0; j < kTileSpheres; ++j) {
             _Float16 slots[kLiftSlots];
@@ -954,6 +967,7 @@ int upload_scene(rt_ctx *ctx, const Object *objs, int n, bool *cache_hit = nullp
     RT_TRY(upload(ctx, ctx->word_bounds, balls));
     RT_TRY(upload(ctx, ctx->round_runs, round_runs(balls)));
     RT_TRY(upload(ctx, ctx->tile_obj, tileset.obj));
+    RT_TRY(upload(ctx, ctx->tile_rank, tileset.rank));
     RT_TRY(upload(ctx, ctx->sph_obj, sph_obj));
     RT_TRY(upload(ctx, ctx->quads, quads));
     RT_TRY(upload(ctx, ctx->mats, mats));
@@ -1021,6 +1035,7 @@ void fill_params(const rt_ctx *ctx, const Uniforms *u, TraceParams &P) {
     P.word_bounds = ctx->word_bounds.ptr;
     P.round_runs = ctx->round_runs.ptr;
     P.tile_obj = ctx->tile_obj.ptr;
+    P.tile_rank = ctx->tile_rank.ptr;
     P.ntiles = ctx->ntiles;
     P.lift = ctx->lift;
     P.nobj = ctx->nobj;
@@ -1225,6 +1240,7 @@ RT_API void rt_destroy(rt_ctx *ctx) {
     (void)hipFree(ctx->word_bounds.ptr);
     (void)hipFree(ctx->round_runs.ptr);
     (void)hipFree(ctx->tile_obj.ptr);
+    (void)hipFree(ctx->tile_rank.ptr);
     (void)hipFree(ctx->sph_obj.ptr);
     (void)hipFree(ctx->quads.ptr);
     (void)hipFree(ctx->mats.ptr);

@@ -19,6 +19,7 @@
 namespace rt {
 
 typedef float f4v __attribute__((ext_vector_type(4)));  // one compact sphere record, 16 bytes
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 
 struct V3 { float x, y, z; };
 struct V4 { float x, y, z, w; };

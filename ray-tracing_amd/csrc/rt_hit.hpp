@@ -21,7 +21,7 @@ constexpr int kListOffset = kRoundWords * 64;        // after a wave's candidate
 constexpr int kBestOffset = kListOffset + 64;        // ... and 64 x 64 bits of (distance, slot) minima (resolve_balanced)
 constexpr int kMaskWordsPerWave = kBestOffset + 128; // LDS words per wave
 #ifndef RT_FEW_RAYS
-#define RT_FEW_RAYS 8
+#define RT_FEW_RAYS 12
 #endif
 #ifndef RT_REST_POOLED
 #define RT_REST_POOLED 64
@@ -1731,7 +1731,7 @@ RT_DEV int closest_sphere_direct(const TraceParams &P, Fetch<kFetchTiledDirect> 
     const float s = __builtin_amdgcn_rsqf(a) * kDirScale;
     const V3 dn = v3(d.x * s, d.y * s, d.z * s);
     const int lane = threadIdx.x & 63;
-    int ibest = -1, obest = 0;   // slot in tile order and object index of the best hit so far
+    int ibest = -1;   // slot in tile order of the best hit so far
     float nskip = __builtin_inff();
     const const_f4_ptr frames = (const_f4_ptr)(uintptr_t)P.tile_frames;
     const const_f4_ptr groups = frames + kTileFrameVec4 * P.ntiles;
@@ -1795,14 +1795,15 @@ RT_DEV int closest_sphere_direct(const TraceParams &P, Fetch<kFetchTiledDirect> 
             const f4v fa = frames[kTileFrameVec4 * t], fb = frames[kTileFrameVec4 * t + 1];
             const f4v *tile = f.tiles + (size_t)t * kTileVec4;
             const int n = __builtin_popcountll(touching);
-            if (n <= kFewRays && P.nobj <= (1 << 23)) {
+            if (n <= kFewRays) {
                 // A few rays against the tile's 512 slots: no filter at all.  Every lane holds the strict records of eight
                 // slots (eight coalesced loads, all in flight at once) and evaluates the reference's own discriminant
                 // (Lib.metal:216-224, the same operations in the same order) for one ray after the other, the ray's
-                // numbers broadcast from its lane; a lane that finds an accepted root offers (root, object, slot) to the
-                // ray's 64-bit minimum in LDS, root in the upper half -- positive floats order like unsigned integers,
-                // so the minimum is the smallest root and, among equal roots, the lowest object index, which is the
-                // reference's choice (Shaders.metal:17-22; see resolve_balanced for why the root a sphere offers does
+                // numbers broadcast from its lane; a lane that finds an accepted root offers (root, place of the slot's
+                // object index among the tile's, slot) to the ray's 64-bit minimum in LDS, root in the upper half --
+                // positive floats order like unsigned integers, so the minimum is the smallest root and, among equal
+                // roots, the lowest object index, which is the reference's choice (the places come with the records,
+                // 16 bits a slot: no load stands between a root and its offer) (Shaders.metal:17-22; see resolve_balanced for why the root a sphere offers does
                 // not depend on the best so far).
                 // (Asking for the next visited tile's records while this one is worked on was measured: the second set of
                 // registers spills, -29 % with tiles of 512 slots, -6 % with 256.)
@@ -1813,6 +1814,8 @@ RT_DEV int closest_sphere_direct(const TraceParams &P, Fetch<kFetchTiledDirect> 
                 f4v rec[kPerLane];
 #pragma unroll
                 for (int i = 0; i < kPerLane; ++i) rec[i] = tile[kTileLifted + 64 * i + lane];
+                static_assert(kTileBlocks <= 8, "eight 16-bit places per lane");
+                const u4v ranks = ((const u4v *)P.tile_rank)[t * 64 + lane];
                 const f4v *kb = block_boxes + 2 * (t * kTileBlocks + (lane & (kTileBlocks - 1)));
                 const f4v kbm = kb[0], kbh = kb[1];
                 const bool holds_block = lane < ((int)fb.y + 63) / 64;
@@ -1842,9 +1845,9 @@ RT_DEV int closest_sphere_direct(const TraceParams &P, Fetch<kFetchTiledDirect> 
                         if (disc >= 0.0f) {
                             float root, nbest = __builtin_inff();
                             if (sphere_root(disc, b, q, kMaxFloat, nbest, root)) {
-                                const uint32_t kl = (uint32_t)(64 * i + lane);
-                                const uint32_t obj = (uint32_t)P.tile_obj[t * kTileSpheres + (int)kl];
-                                atomicMin(&offer[L], ((unsigned long long)__float_as_uint(root) << 32) | (obj << 9) | kl);  // kl < 512
+                                const uint32_t kl = (uint32_t)(64 * i + lane);   // < 512
+                                const uint32_t place = (ranks[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                                atomicMin(&offer[L], ((unsigned long long)__float_as_uint(root) << 32) | (place << 9) | kl);
                             }
                         }
                     }
@@ -1855,11 +1858,11 @@ RT_DEV int closest_sphere_direct(const TraceParams &P, Fetch<kFetchTiledDirect> 
                 if (touch) {
                     const unsigned long long key = offer[lane];
                     const float root = __uint_as_float((uint32_t)(key >> 32));
-                    const int obj = (int)((uint32_t)key >> 9);
-                    if (key != ~0ull && (root < tbest || (root == tbest && ibest >= 0 && obj < obest))) {
+                    const int k = t * kTileSpheres + (int)((uint32_t)key & 511u);
+                    // (an equal distance in another tile: the object indices are looked up only then)
+                    if (key != ~0ull && (root < tbest || (root == tbest && ibest >= 0 && P.tile_obj[k] < P.tile_obj[ibest]))) {
                         tbest = root;
-                        ibest = t * kTileSpheres + (int)((uint32_t)key & 511u);
-                        obest = obj;
+                        ibest = k;
                         nskip = __builtin_inff();  // (the numerator did not travel: no division is skipped on its account)
                     }
                 }
@@ -1923,11 +1926,9 @@ RT_DEV int closest_sphere_direct(const TraceParams &P, Fetch<kFetchTiledDirect> 
                 bool tie;
                 if (sphere_root_any_order(disc, b, dv, tbest, nskip, n, root, tie)) {
                     const int k = t * kTileSpheres + kl;
-                    const int obj = P.tile_obj[k];
-                    if (!tie || (ibest >= 0 && obj < obest)) {
+                    if (!tie || (ibest >= 0 && P.tile_obj[k] < P.tile_obj[ibest])) {
                         tbest = root;
                         ibest = k;
-                        obest = obj;
                         nskip = n * (1.0f + 0x1p-22f);
                     }
                 }

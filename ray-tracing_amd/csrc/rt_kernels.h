@@ -57,6 +57,9 @@ struct TraceParams {
                                 // and after those for each of the kTileBlocks blocks of 64 slots of every tile (a tile's
                                 // slots are ordered so that a block's spheres are neighbours in space)
     const int *tile_obj;    // [ntiles * 512] object index of each slot in tile order (-1: padding)
+    const uint16_t *tile_rank;  // [ntiles * 512] per tile 512 entries, for lane l the entries 8 l + i: the place of the
+                                // object index of slot 64 i + l among the tile's object indices in ascending order
+                                // (what equal distances inside a tile are decided by; closest_sphere_direct)
     int ntiles;
     int stage_mats;         // matrix-core kind: sph_obj and mats are staged in LDS too (the launch reserved the room)
     int nobj;               // objects (length of mats)
