@@ -475,8 +475,12 @@ TileSet build_tiles(const std::vector<float4> &sph, const std::vector<int> &sph_
         order_blocks(m, 0, (int)m.size());
         members.push_back(m);
     }
+    // spheres no tile's frame fits (a ground sphere; anything not finite) get tiles of their own: in a tile of ordinary
+    // spheres one of them would make the tile's box infinite, and every ray would be put through that tile's filter
+    bool own_tile = false;
     for (int i : irregular) {
-        if (members.empty() || (int)members.back().size() >= kTileSpheres) members.push_back({});
+        if (!own_tile || (int)members.back().size() >= kTileSpheres) members.push_back({});
+        own_tile = true;
         members.back().push_back(i);
     }
     double diag = 0.0;

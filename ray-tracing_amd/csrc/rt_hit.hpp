@@ -30,6 +30,7 @@ constexpr int kRestPooled = RT_REST_POOLED;  // dense rounds: candidates in the 
 constexpr int kRestPerLane = 12;   // dense rounds: candidates per lane after the prune up to which every lane resolves its own
 constexpr int kFewRays = RT_FEW_RAYS;  // tiled kind read in place: rays of a wave that touch a tile up to which every lane tests its share of the tile's
                                        // slots exactly for one ray after the other (closest_sphere_direct); more go through the matrix-core filter
+constexpr int kFewSpheres = 8;      // tiled kind read in place: spheres in a tile up to which no filter runs and all are candidates
 constexpr int kDenseWordBits = 8;  // candidates in a word of 32 spheres from which the word counts as dense (closest_sphere)
 
 // Filter margins (see closest_sphere).  kDirScale inflates the b side of both filters; the c side is inflated
@@ -1787,6 +1788,7 @@ RT_DEV int closest_sphere_direct(const TraceParams &P, Fetch<kFetchTiledDirect> 
                 }
             }
         }
+        prof.lap(1);   // (stamped build) the box tests count with the filter
         for (uint64_t tiles = __builtin_amdgcn_ballot_w64((set_lo | set_hi) != 0u); tiles != 0; tiles &= tiles - 1) {
             const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(tiles));
             const int t = t0 + j;
@@ -1871,11 +1873,17 @@ RT_DEV int closest_sphere_direct(const TraceParams &P, Fetch<kFetchTiledDirect> 
             }
             const LiftFrame F = {fa.x, fa.y, fa.z, fa.w};
             const int count = (int)fb.y;
+            uint32_t nz;
+            if (count <= kFewSpheres) {
+                // a handful of spheres (the tile of the ground sphere, which every ray visits): no filter, every one of them
+                // is a candidate of every ray
+                wave_masks[lane] = ~(0xFFFFFFFFu >> count);
+                nz = count > 0 ? 1u : 0u;
+            } else {
             float oo;
             h8 slots[4];
             lift_ray_near_slots(F, fb.z, o, dn, kMfmaSlack, kNearSlack, oo, slots);
             const bool general = __builtin_amdgcn_ballot_w64(touch && !(oo <= fb.x)) != 0;  // wave-uniform
-            uint32_t nz;
             if (general) {
                 RayGeneral y = {o, dn};
                 TileStrict ts = {tile + kTileLifted};
@@ -1897,6 +1905,7 @@ RT_DEV int closest_sphere_direct(const TraceParams &P, Fetch<kFetchTiledDirect> 
                     work.blocks += 2u * (uint32_t)nblk;
                 }
                 __builtin_amdgcn_s_setprio(1);
+            }
             }
             if (!touch) nz = 0;
             prof.lap(1);
