@@ -80,5 +80,5 @@ text("rank_share.txt", prefix + "_rank_share.txt", "tools/exp_rank_share.py: one
 text("narrow.txt", prefix + "_narrow.txt", "tools/exp_narrow.py: the staged matrix kind with its sphere filter at half width for the rays that can touch the box of the scene's small spheres (RT_OPT_NARROW 1) against full width (0)")
 text("narrow_tiled.txt", prefix + "_narrow_tiled.txt", "tools/exp_narrow_tiled.py: tiles read in place by the waves whose rays can touch them (RT_OPT_NARROW 1, path 5) against all tiles streamed through LDS (0, path 4)")
 text("box_selftest.txt", prefix + "_box_selftest.txt", "tools/exp_box_selftest.py 4 2048 8: rays the box tests leave out against the exact hit test, with the library's padding (2^0) and with less")
-text("tile_box_margin.txt", prefix + "_tile_box_margin.txt", "tools/exp_tile_box_margin.py: rt_selftest_tile_boxes (tiles read in place), 8 seeds, at the shipped allowances (radius growth 64u D^2) and at a half, a quarter, an eighth of them")
+text("tile_box_margin.txt", prefix + "_tile_box_margin.txt", "tools/exp_tile_box_margin.py: rt_selftest_tile_boxes (tiles read in place), 8 seeds, at the shipped allowances (radius growth 64u D^2) and at a half, a quarter, an eighth of them (the bound on the roundings of the reference asks for 17u)")
 print("collected under", prefix, "kernel source id", kid)
